@@ -1,0 +1,201 @@
+// TEST INFRASTRUCTURE ONLY. Not part of the product; nothing outside tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg may use anything
+// under oracle/.
+//
+// Harness around the UNMODIFIED reference headers, compiled from where they lie
+// (-I/root/reference/include); the binary lands in oracle/_ref/ (git-ignored).
+// It drives the reference's own Scene factories, BVH builder and traceRay and
+// dumps what the parity fixtures need.  No reference source is copied: the only
+// things taken from the reference are its headers, by #include.
+//
+// The reference selects brute force vs BVH with an unconditional
+// `#define USE_BVH 0` (include/common.hpp:14).  common.hpp is include-guarded,
+// so including it first and re-defining the macro before scene.hpp makes the
+// `#if USE_BVH` blocks in include/scene.hpp:41,92,154 see the value chosen by
+// -DREF_USE_BVH=0|1 on the command line of this harness.
+//
+// The per-pixel loop restates src/main.cpp:75-94 (render/putPixel) with the
+// canvas size and recursion depth as run-time arguments; src/main.cpp itself
+// cannot be used because the canvas is a compile-time sized global.
+#include "common.hpp"
+#undef USE_BVH
+#define USE_BVH REF_USE_BVH
+#include "scene.hpp"
+
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+namespace {
+
+uint64_t fnv1a(const void *data, size_t n, uint64_t h = 1469598103934665603ull) {
+    const unsigned char *p = static_cast<const unsigned char *>(data);
+    for (size_t i = 0; i < n; i++) {
+        h ^= p[i];
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+
+void dump(const std::string &path, const void *data, size_t n) {
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f || fwrite(data, 1, n, f) != n) {
+        fprintf(stderr, "ref_harness: cannot write %s\n", path.c_str());
+        exit(2);
+    }
+    fclose(f);
+}
+
+struct Out {
+    int W, H;
+    std::vector<int32_t> hit;   // H*W, row i = -y + H/2 - 1, col j = x + W/2
+    std::vector<int32_t> rgb;   // H*W*3 unclamped Color ints
+    std::vector<double> t;      // H*W primary closestT (INF on miss)
+};
+
+// One column strip, as the reference's render(scene, xMin, xMax) does it.
+void strip(Scene scene, int xMin, int xMax, int depth, Out *out) {
+    const int W = out->W, H = out->H;
+    for (int x = xMin; x < xMax; x++) {
+        // y spans [-H/2, H/2) for even H (src/main.cpp:77); an odd H gets its bottom row too.
+        for (int y = -(H - H / 2); y < H / 2; y++) {
+            Vector3 ray = scene.toViewport(x, y, W, H)
+                              .rotateX(scene.cameraRotation.x)
+                              .rotateY(scene.cameraRotation.y)
+                              .rotateZ(scene.cameraRotation.z);
+#if USE_BVH
+            tuple<bool, double, int> prim =
+                scene.bvh.intersectRay(scene.cameraPosition, ray, 1.0, INFINITY, 0);
+#else
+            tuple<bool, double, int> prim =
+                scene.closestIntersection(scene.cameraPosition, ray, 1.0, INFINITY);
+#endif
+            Color c = scene.traceRay(scene.cameraPosition, ray, 1.0, INFINITY, depth);
+            size_t i = static_cast<size_t>(-y + H / 2 - 1);
+            size_t j = static_cast<size_t>(x + W / 2);
+            size_t k = i * static_cast<size_t>(W) + j;
+            out->hit[k] = std::get<2>(prim);
+            out->t[k] = std::get<1>(prim);
+            out->rgb[3 * k + 0] = c.r;
+            out->rgb[3 * k + 1] = c.g;
+            out->rgb[3 * k + 2] = c.b;
+        }
+    }
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    if (argc < 7) {
+        fprintf(stderr,
+                "usage: %s <teapot|bunny|erato|dragon|aurelius> <dir holding scenes/NAME.obj> "
+                "<W> <H> <depth> <out_prefix|-> [threads]\n",
+                argv[0]);
+        return 2;
+    }
+    std::string name = argv[1];
+    std::string root = argv[2];
+    Out out;
+    out.W = atoi(argv[3]);
+    out.H = atoi(argv[4]);
+    int depth = atoi(argv[5]);
+    std::string prefix = argv[6];
+    int threads = argc > 7 ? atoi(argv[7]) : 8;
+
+    // out_prefix is resolved against the original cwd, the scene factories
+    // against `root` (they hard-code "scenes/NAME.obj", include/scene.hpp:262).
+    char cwd[4096];
+    if (!getcwd(cwd, sizeof cwd)) return 2;
+    if (prefix != "-" && prefix[0] != '/') prefix = std::string(cwd) + "/" + prefix;
+    if (chdir(root.c_str()) != 0) {
+        fprintf(stderr, "ref_harness: cannot chdir to %s\n", root.c_str());
+        return 2;
+    }
+
+    Scene scene;
+    try {
+        if (name == "teapot") scene = Scene::teapot();
+        else if (name == "bunny") scene = Scene::bunny();
+        else if (name == "erato") scene = Scene::erato();
+        else if (name == "dragon") scene = Scene::dragon();
+        else if (name == "aurelius") scene = Scene::aurelius();
+        else { fprintf(stderr, "unknown scene %s\n", name.c_str()); return 2; }
+    } catch (const char *e) {
+        std::cerr << e;
+        return -1;
+    }
+
+    size_t npx = static_cast<size_t>(out.W) * static_cast<size_t>(out.H);
+    out.hit.assign(npx, -2);
+    out.rgb.assign(npx * 3, 0);
+    out.t.assign(npx, 0.0);
+
+    auto t0 = std::chrono::high_resolution_clock::now();
+    if (out.W > 0 && out.H > 0) {
+        std::vector<std::thread> pool;
+        int start = -out.W / 2;
+        // W/threads columns per strip like src/main.cpp:38; the last strip
+        // takes the remainder so that any W renders completely.
+        int step = out.W / threads;
+        for (int i = 0; i < threads; i++) {
+            int x0 = start + i * step;
+            int x1 = (i == threads - 1) ? (out.W - out.W / 2) : x0 + step;
+            pool.emplace_back(strip, scene, x0, x1, depth, &out);
+        }
+        for (auto &th : pool) th.join();
+    }
+    auto t1 = std::chrono::high_resolution_clock::now();
+    double secs = std::chrono::duration<double>(t1 - t0).count();
+
+    std::vector<unsigned char> rgb8(npx * 3);
+    for (size_t k = 0; k < npx; k++) {
+        Color c = Color(out.rgb[3 * k], out.rgb[3 * k + 1], out.rgb[3 * k + 2]).normalize();
+        rgb8[3 * k + 0] = static_cast<unsigned char>(c.r);
+        rgb8[3 * k + 1] = static_cast<unsigned char>(c.g);
+        rgb8[3 * k + 2] = static_cast<unsigned char>(c.b);
+    }
+
+    printf("mode %s\n", USE_BVH ? "bvh" : "brute");
+    printf("triangles %zu\n", scene.triangles.size());
+    printf("frame_seconds %.3f threads %d\n", secs, threads);
+    printf("hit_fnv %016llx\n", static_cast<unsigned long long>(fnv1a(out.hit.data(), npx * 4)));
+    printf("rgb_i32_fnv %016llx\n", static_cast<unsigned long long>(fnv1a(out.rgb.data(), npx * 12)));
+    printf("rgb_u8_fnv %016llx\n", static_cast<unsigned long long>(fnv1a(rgb8.data(), npx * 3)));
+    printf("t_fnv %016llx\n", static_cast<unsigned long long>(fnv1a(out.t.data(), npx * 8)));
+#if USE_BVH
+    printf("nodes_used %zu\n", scene.bvh.nodesUsed);
+    static_assert(sizeof(BVHNode) == 64, "BVHNode layout");
+    printf("nodes_fnv %016llx\n", static_cast<unsigned long long>(
+                                      fnv1a(scene.bvh.nodes, scene.bvh.nodesUsed * sizeof(BVHNode))));
+    printf("indices_fnv %016llx\n",
+           static_cast<unsigned long long>(fnv1a(scene.bvh.indices.data(), scene.bvh.indices.size() * 8)));
+#endif
+    {
+        // geometry as the Triangle ctor left it: v0 v1 v2 normal centroid (15 doubles)
+        uint64_t h = 1469598103934665603ull;
+        for (Triangle &tr : scene.triangles) {
+            double g[15] = {tr.v0.x, tr.v0.y, tr.v0.z, tr.v1.x, tr.v1.y, tr.v1.z, tr.v2.x, tr.v2.y,
+                            tr.v2.z, tr.normal.x, tr.normal.y, tr.normal.z, tr.centroid.x,
+                            tr.centroid.y, tr.centroid.z};
+            h = fnv1a(g, sizeof g, h);
+        }
+        printf("geometry_fnv %016llx\n", static_cast<unsigned long long>(h));
+    }
+
+    if (prefix != "-") {
+        dump(prefix + ".hit.i32", out.hit.data(), npx * 4);
+        dump(prefix + ".rgb.i32", out.rgb.data(), npx * 12);
+        dump(prefix + ".rgb.u8", rgb8.data(), npx * 3);
+        dump(prefix + ".t.f64", out.t.data(), npx * 8);
+#if USE_BVH
+        dump(prefix + ".nodes.bin", scene.bvh.nodes, scene.bvh.nodesUsed * sizeof(BVHNode));
+        dump(prefix + ".indices.u64", scene.bvh.indices.data(), scene.bvh.indices.size() * 8);
+#endif
+    }
+    return 0;
+}
