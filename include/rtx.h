@@ -1,0 +1,197 @@
+/* rtx.h -- C ABI of the MI355X render path.
+ *
+ * Drop-in for the reference's threaded per-pixel loop: everything
+ * `void render(Scene scene, int xMin, int xMax)` (src/main.cpp:18,75-88) does for
+ * one frame -- camera ray, BVH closest hit, shadow rays, shading, the reflection
+ * blend, putPixel -- runs on the GPU behind rtx_render().  Scene loading, the
+ * binned-SAH BVH build and image output stay on the host.
+ *
+ * Plain pointers and sizes only; no exceptions cross this boundary.  Every call
+ * returns RTX_OK (0) or a negative rtx_status; rtx_last_error() gives the text for
+ * the calling thread.  (The reference throws string literals that main() prints
+ * and turns into exit code -1, src/main.cpp:27-32,65-70.)
+ *
+ * Threading: a scene handle may be used from any thread, one render at a time per
+ * handle.  All calls are synchronous unless a stream is passed.
+ */
+#ifndef RTX_H
+#define RTX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rtx_status {
+    RTX_OK = 0,
+    RTX_ERR_INVALID = -1,     /* bad argument                                   */
+    RTX_ERR_IO = -2,          /* "Failed to open file." and friends             */
+    RTX_ERR_DEVICE = -3,      /* HIP runtime error                              */
+    RTX_ERR_UNSUPPORTED = -4, /* valid input this build cannot handle           */
+    RTX_ERR_NOMEM = -5
+} rtx_status;
+
+/* ---- host-side scene data ------------------------------------------------------ */
+
+/* BVHNode as the reference lays it out (include/bvh.hpp:25-30): 64 bytes.
+ * count == 0: inner node, children are `first` and `first + 1`;
+ * count  > 0: leaf over indices[first .. first+count). */
+typedef struct rtx_bvh_node {
+    double bmin[3];
+    double bmax[3];
+    uint64_t first;
+    uint64_t count;
+} rtx_bvh_node;
+
+/* Point (include/light.hpp:8-11): v = position; Directional (:13-16): v = direction. */
+typedef struct rtx_light {
+    double intensity;
+    double v[3];
+} rtx_light;
+
+/* What `Scene` holds (include/scene.hpp:15-23), as plain arrays.  Triangle index i
+ * below is the reference's index into Scene::triangles, and it is the id that
+ * rtx_render reports. */
+typedef struct rtx_scene_desc {
+    uint64_t n_triangles;
+    const double *vertices;      /* [n][9]  v0 v1 v2                                  */
+    const double *normals;       /* [n][3]  as the Triangle ctor computes them
+                                    (include/triangle.hpp:21-23); NULL = compute here */
+    const int32_t *colors;       /* [n][3]  Color r g b (ints, not clamped)            */
+    const int32_t *specularity;  /* [n]     -1 = no specular term                      */
+    const double *reflectivity;  /* [n]     < 0 = no reflection                        */
+    /* BVH built by the caller with the reference builder; NULL/0 = build it here with
+     * this library's restatement of that builder (identical arrays). */
+    uint64_t n_nodes;
+    const rtx_bvh_node *nodes;
+    const uint64_t *indices;     /* [n]                                               */
+    double viewport[3];
+    double camera_position[3];
+    double camera_rotation_deg[3];
+    int32_t background[3];
+    double ambient;
+    uint32_t n_point_lights;
+    const rtx_light *point_lights;
+    uint32_t n_directional_lights;
+    const rtx_light *directional_lights;
+    int32_t device;              /* HIP device ordinal, -1 = current device            */
+} rtx_scene_desc;
+
+/* A host scene: the result of parseOBJ plus one scene factory plus the BVH build
+ * (include/scene.hpp:213-253, :255-448, include/bvh.hpp:84-162).  Owns its arrays. */
+typedef struct rtx_host_scene rtx_host_scene;
+
+/* Replaces Scene::parseOBJ(path) + Scene::<preset>() (include/scene.hpp:213-448).
+ * preset: "teapot", "bunny", "erato", "dragon" or "aurelius" -- camera position,
+ * rotation (0, 0.1, 0) deg, white background, ambient 0.2, one directional light
+ * 0.5 * (0,1,-1) and the last-10-triangles material overrides.  Prints the
+ * reference's "[ TRI ] n triangles." / "[ BVH ] s seconds." lines when verbose. */
+int rtx_host_scene_load_obj(const char *obj_path, const char *preset, int verbose, rtx_host_scene **out);
+
+/* The stand-in for a missing mesh: a seeded procedural closed surface with exactly
+ * n_triangles - 10 faces inside the 10-triangle open box of tools/range.py:40-54,
+ * framed for `preset`'s camera.  Written as an .obj in the reference's dialect when
+ * obj_path_out != NULL (no trailing newline), and/or loaded like the call above.
+ * No counterpart in the reference (its bunny/dragon/erato/aurelius meshes are not
+ * redistributable with this repository). */
+int rtx_host_scene_standin(const char *preset, uint64_t n_triangles, uint64_t seed, const char *obj_path_out,
+                           int verbose, rtx_host_scene **out);
+
+/* Scene from caller arrays (copies them; builds normals/BVH when absent). */
+int rtx_host_scene_from_desc(const rtx_scene_desc *desc, rtx_host_scene **out);
+
+/* Borrow the arrays of a host scene as a desc (valid until the host scene is freed). */
+int rtx_host_scene_desc(const rtx_host_scene *hs, rtx_scene_desc *out);
+/* Tree depth of the BVH (root = 0). */
+int32_t rtx_host_scene_bvh_depth(const rtx_host_scene *hs);
+/* Camera / light edits on a loaded scene (the reference edits Scene members directly). */
+int rtx_host_scene_set_camera(rtx_host_scene *hs, const double position[3], const double rotation_deg[3]);
+int rtx_host_scene_set_lights(rtx_host_scene *hs, double ambient, uint32_t n_point, const rtx_light *point,
+                              uint32_t n_directional, const rtx_light *directional);
+void rtx_host_scene_free(rtx_host_scene *hs);
+
+/* ---- device scene --------------------------------------------------------------- */
+
+typedef struct rtx_scene rtx_scene;
+
+/* Flattens the scene into the device layout and uploads it to desc->device.
+ * Takes the place of passing `Scene` by value to each render thread
+ * (src/main.cpp:46). */
+int rtx_scene_create(const rtx_scene_desc *desc, rtx_scene **out);
+int rtx_scene_create_from_host(const rtx_host_scene *hs, int32_t device, rtx_scene **out);
+void rtx_scene_destroy(rtx_scene *scene);
+/* Bytes of HBM held by the scene (nodes + triangles + materials + lights). */
+uint64_t rtx_scene_device_bytes(const rtx_scene *scene);
+
+/* ---- render ---------------------------------------------------------------------- */
+
+enum {
+    RTX_TRAVERSAL_REFERENCE = 0, /* visits exactly the nodes BVH::intersectRay visits      */
+    RTX_TRAVERSAL_PRUNED = 1     /* near-first order + distance pruning, same results      */
+};
+
+enum {
+    RTX_LAYOUT_ROW_MAJOR = 0,    /* out[row][col], row 0 = top (putPixel, src/main.cpp:90-94) */
+    RTX_LAYOUT_PACKED_TILES = 1  /* out[local tile][tile_h][tile_w]: only this rank's tiles   */
+};
+
+/* The arguments of render() + the compile-time constants of src/main.cpp:8-9,83. */
+typedef struct rtx_render_params {
+    int32_t width, height;       /* CANVAS_WIDTH / CANVAS_HEIGHT                              */
+    int32_t x0, x1, y0, y1;      /* pixel window, columns [x0,x1) rows [y0,y1); all 0 = frame */
+    int32_t depth;               /* recursionDepth of traceRay (3 in src/main.cpp:83), 0..7   */
+    int32_t spp;                 /* 1 = the reference; > 1 = jittered supersampling           */
+    uint64_t seed;               /* jitter seed                                               */
+    int32_t traversal;           /* RTX_TRAVERSAL_*                                           */
+    /* image-space sharding: the frame is cut into tile_w x tile_h tiles (multiples of 8),
+     * numbered row-major; this call renders tile k iff k % tile_count == tile_rank.
+     * tile_count <= 1 renders every tile. */
+    int32_t tile_w, tile_h, tile_rank, tile_count;
+    int32_t layout;              /* RTX_LAYOUT_*                                              */
+} rtx_render_params;
+
+/* Work counters of one render (all rays: closest-hit and shadow queries). */
+typedef struct rtx_stats {
+    uint64_t primary_rays, reflection_rays, shadow_rays, shadow_occluded, closest_hits;
+    uint64_t node_visits, box_hits, leaf_visits, triangle_tests;
+    double kernel_ms;            /* HIP-event time of the render kernel(s)                    */
+} rtx_stats;
+
+void rtx_render_params_default(rtx_render_params *p, int32_t width, int32_t height);
+
+/* Size in pixels of the output buffers for these params (row-major: W*H; packed:
+ * owned tiles * tile_w * tile_h). */
+uint64_t rtx_output_pixels(const rtx_render_params *p);
+
+/* One frame into HOST buffers.  Replaces the 8-thread render() fan-out and join
+ * (src/main.cpp:45-52).  rgb_out: 3 bytes per pixel, clamped as saveCanvas does
+ * (src/main.cpp:107); hit_id_out (nullable): primary-ray triangle id or -1;
+ * stats (nullable): asks the kernel to count its work. */
+int rtx_render(rtx_scene *scene, const rtx_render_params *p, uint8_t *rgb_out, int32_t *hit_id_out,
+               rtx_stats *stats);
+
+/* Same frame into DEVICE buffers, asynchronous on `stream` (a hipStream_t, NULL =
+ * default stream).  d_rgb_i32 (nullable): the unclamped Color ints, 3 per pixel
+ * (the reference's canvas, src/main.cpp:16); d_t (nullable): primary closestT.
+ * d_stats (nullable): device pointer to an rtx_stats the kernel adds into. */
+int rtx_render_device(rtx_scene *scene, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id,
+                      void *d_rgb_i32, void *d_t, void *d_stats, void *stream);
+
+/* After an all-gather of `n_ranks` packed tile buffers ([rank][local tile][tile_h][tile_w][3]),
+ * writes the row-major frame.  Device pointers; asynchronous on `stream`.
+ * No counterpart in the reference (its threads write one shared canvas). */
+int rtx_untile(const rtx_render_params *p, int32_t n_ranks, const void *d_gathered_u8, void *d_rgb_u8,
+               int32_t bytes_per_pixel, void *stream);
+
+/* saveCanvas (src/main.cpp:96-116): binary P6, "P6\n<W> <H> 255\n" + rows. */
+int rtx_save_ppm(const char *path, int32_t width, int32_t height, const uint8_t *rgb);
+
+const char *rtx_last_error(void);
+const char *rtx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTX_H */

@@ -1,0 +1,339 @@
+"""ctypes binding of librtx.so (the C ABI in include/rtx.h).
+
+Mirrors what the reference's main() does around its render threads
+(src/main.cpp:24-73): load a scene (Scene::teapot() etc., include/scene.hpp:255-448),
+render frames, save a PPM.  There is no CPU fallback: if librtx.so is missing or a
+call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librtx.so")
+
+TRAVERSAL_REFERENCE = 0
+TRAVERSAL_PRUNED = 1
+LAYOUT_ROW_MAJOR = 0
+LAYOUT_PACKED_TILES = 1
+
+# face counts of the reference's scenes (include/scene.hpp:255,294,333,372,411)
+SCENE_TRIANGLES = {"teapot": 6330, "bunny": 144056, "erato": 412508, "dragon": 871316, "aurelius": 1704768}
+
+
+class RtxError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"rtx error {code}: {message}")
+        self.code = code
+
+
+class BvhNode(C.Structure):
+    _fields_ = [("bmin", C.c_double * 3), ("bmax", C.c_double * 3), ("first", C.c_uint64), ("count", C.c_uint64)]
+
+
+class Light(C.Structure):
+    _fields_ = [("intensity", C.c_double), ("v", C.c_double * 3)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [
+        ("n_triangles", C.c_uint64),
+        ("vertices", C.POINTER(C.c_double)),
+        ("normals", C.POINTER(C.c_double)),
+        ("colors", C.POINTER(C.c_int32)),
+        ("specularity", C.POINTER(C.c_int32)),
+        ("reflectivity", C.POINTER(C.c_double)),
+        ("n_nodes", C.c_uint64),
+        ("nodes", C.POINTER(BvhNode)),
+        ("indices", C.POINTER(C.c_uint64)),
+        ("viewport", C.c_double * 3),
+        ("camera_position", C.c_double * 3),
+        ("camera_rotation_deg", C.c_double * 3),
+        ("background", C.c_int32 * 3),
+        ("ambient", C.c_double),
+        ("n_point_lights", C.c_uint32),
+        ("point_lights", C.POINTER(Light)),
+        ("n_directional_lights", C.c_uint32),
+        ("directional_lights", C.POINTER(Light)),
+        ("device", C.c_int32),
+    ]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32),
+        ("x0", C.c_int32), ("x1", C.c_int32), ("y0", C.c_int32), ("y1", C.c_int32),
+        ("depth", C.c_int32), ("spp", C.c_int32), ("seed", C.c_uint64),
+        ("traversal", C.c_int32),
+        ("tile_w", C.c_int32), ("tile_h", C.c_int32), ("tile_rank", C.c_int32), ("tile_count", C.c_int32),
+        ("layout", C.c_int32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "primary_rays", "reflection_rays", "shadow_rays", "shadow_occluded", "closest_hits",
+        "node_visits", "box_hits", "leaf_visits", "triangle_tests")] + [("kernel_ms", C.c_double)]
+
+    @property
+    def rays(self) -> int:
+        return self.primary_rays + self.reflection_rays + self.shadow_rays
+
+    def as_dict(self) -> dict:
+        d = {n: getattr(self, n) for n, _ in self._fields_}
+        d["rays"] = self.rays
+        return d
+
+
+# every symbol include/rtx.h declares
+EXPORTS = (
+    "rtx_host_scene_load_obj", "rtx_host_scene_standin", "rtx_host_scene_from_desc", "rtx_host_scene_desc",
+    "rtx_host_scene_bvh_depth", "rtx_host_scene_set_camera", "rtx_host_scene_set_lights", "rtx_host_scene_free",
+    "rtx_scene_create", "rtx_scene_create_from_host", "rtx_scene_destroy", "rtx_scene_device_bytes",
+    "rtx_render_params_default", "rtx_output_pixels", "rtx_render", "rtx_render_device", "rtx_untile",
+    "rtx_save_ppm", "rtx_last_error", "rtx_version",
+)
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Loads librtx.so (built in-tree by ray_tracer_amd/csrc/Makefile); raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RtxError(-3, f"{LIB_PATH} is missing: build it with `make -C ray_tracer_amd/csrc`")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.rtx_last_error.restype = C.c_char_p
+    L.rtx_version.restype = C.c_char_p
+    L.rtx_host_scene_load_obj.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.rtx_host_scene_standin.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.rtx_host_scene_from_desc.argtypes = [C.POINTER(SceneDesc), C.POINTER(vp)]
+    L.rtx_host_scene_desc.argtypes = [vp, C.POINTER(SceneDesc)]
+    L.rtx_host_scene_bvh_depth.argtypes = [vp]
+    L.rtx_host_scene_bvh_depth.restype = C.c_int32
+    L.rtx_host_scene_set_camera.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.rtx_host_scene_set_lights.argtypes = [vp, C.c_double, C.c_uint32, C.POINTER(Light), C.c_uint32, C.POINTER(Light)]
+    L.rtx_host_scene_free.argtypes = [vp]
+    L.rtx_host_scene_free.restype = None
+    L.rtx_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(vp)]
+    L.rtx_scene_create_from_host.argtypes = [vp, C.c_int32, C.POINTER(vp)]
+    L.rtx_scene_destroy.argtypes = [vp]
+    L.rtx_scene_destroy.restype = None
+    L.rtx_scene_device_bytes.argtypes = [vp]
+    L.rtx_scene_device_bytes.restype = C.c_uint64
+    L.rtx_render_params_default.argtypes = [C.POINTER(RenderParams), C.c_int32, C.c_int32]
+    L.rtx_render_params_default.restype = None
+    L.rtx_output_pixels.argtypes = [C.POINTER(RenderParams)]
+    L.rtx_output_pixels.restype = C.c_uint64
+    L.rtx_render.argtypes = [vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]
+    L.rtx_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, vp, vp, vp]
+    L.rtx_untile.argtypes = [C.POINTER(RenderParams), C.c_int32, vp, vp, C.c_int32, vp]
+    L.rtx_save_ppm.argtypes = [C.c_char_p, C.c_int32, C.c_int32, vp]
+    _lib = L
+    return L
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise RtxError(rc, lib().rtx_last_error().decode(errors="replace"))
+
+
+def _dptr(a: np.ndarray, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def make_params(width: int, height: int, *, depth: int = 3, spp: int = 1, seed: int = 0,
+                traversal: int = TRAVERSAL_REFERENCE, window=None, tile=(32, 32), tile_rank: int = 0,
+                tile_count: int = 1, layout: int = LAYOUT_ROW_MAJOR) -> RenderParams:
+    p = RenderParams()
+    lib().rtx_render_params_default(C.byref(p), width, height)
+    p.depth, p.spp, p.seed, p.traversal = depth, spp, seed, traversal
+    if window is not None:
+        p.x0, p.x1, p.y0, p.y1 = window
+    p.tile_w, p.tile_h = tile
+    p.tile_rank, p.tile_count, p.layout = tile_rank, tile_count, layout
+    return p
+
+
+class HostScene:
+    """What the reference holds in `Scene` + `BVH` (include/scene.hpp:15-23, include/bvh.hpp:32-37)."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self._keep = None
+
+    @classmethod
+    def load_obj(cls, path: str, preset: str, verbose: bool = False) -> "HostScene":
+        h = C.c_void_p()
+        _check(lib().rtx_host_scene_load_obj(os.fsencode(path), preset.encode(), int(verbose), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def standin(cls, preset: str, n_triangles: int | None = None, seed: int = 0, obj_path_out: str | None = None,
+                verbose: bool = False) -> "HostScene":
+        h = C.c_void_p()
+        n = SCENE_TRIANGLES[preset] if n_triangles is None else n_triangles
+        out = os.fsencode(obj_path_out) if obj_path_out else None
+        _check(lib().rtx_host_scene_standin(preset.encode(), n, seed, out, int(verbose), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_arrays(cls, vertices, colors, specularity, reflectivity, *, camera_position, camera_rotation_deg=(0, 0, 0),
+                    viewport=(1, 1, 1), background=(255, 255, 255), ambient=0.2, point_lights=(), directional_lights=(),
+                    nodes=None, indices=None) -> "HostScene":
+        v = np.ascontiguousarray(vertices, dtype=np.float64).reshape(-1, 9)
+        n = v.shape[0]
+        col = np.ascontiguousarray(colors, dtype=np.int32).reshape(n, 3)
+        spec = np.ascontiguousarray(specularity, dtype=np.int32).reshape(n)
+        refl = np.ascontiguousarray(reflectivity, dtype=np.float64).reshape(n)
+        d = SceneDesc()
+        d.n_triangles = n
+        d.vertices, d.colors = _dptr(v, C.c_double), _dptr(col, C.c_int32)
+        d.specularity, d.reflectivity = _dptr(spec, C.c_int32), _dptr(refl, C.c_double)
+        keep = [v, col, spec, refl]
+        if nodes is not None:
+            nd = np.ascontiguousarray(nodes)
+            ix = np.ascontiguousarray(indices, dtype=np.uint64)
+            d.n_nodes = nd.shape[0]
+            d.nodes = C.cast(nd.ctypes.data, C.POINTER(BvhNode))
+            d.indices = _dptr(ix, C.c_uint64)
+            keep += [nd, ix]
+        d.viewport[:] = viewport
+        d.camera_position[:] = camera_position
+        d.camera_rotation_deg[:] = camera_rotation_deg
+        d.background[:] = background
+        d.ambient = ambient
+        pl = (Light * max(1, len(point_lights)))()
+        for i, (inten, vec) in enumerate(point_lights):
+            pl[i].intensity = inten
+            pl[i].v[:] = vec
+        dl = (Light * max(1, len(directional_lights)))()
+        for i, (inten, vec) in enumerate(directional_lights):
+            dl[i].intensity = inten
+            dl[i].v[:] = vec
+        d.n_point_lights, d.point_lights = len(point_lights), pl
+        d.n_directional_lights, d.directional_lights = len(directional_lights), dl
+        d.device = -1
+        h = C.c_void_p()
+        _check(lib().rtx_host_scene_from_desc(C.byref(d), C.byref(h)))
+        return cls(h)
+
+    def desc(self) -> SceneDesc:
+        d = SceneDesc()
+        _check(lib().rtx_host_scene_desc(self._h, C.byref(d)))
+        return d
+
+    @property
+    def n_triangles(self) -> int:
+        return int(self.desc().n_triangles)
+
+    @property
+    def n_nodes(self) -> int:
+        return int(self.desc().n_nodes)
+
+    @property
+    def bvh_depth(self) -> int:
+        return int(lib().rtx_host_scene_bvh_depth(self._h))
+
+    def arrays(self) -> dict:
+        """Copies of the scene arrays (numpy)."""
+        d = self.desc()
+        n, m = int(d.n_triangles), int(d.n_nodes)
+        node_dt = np.dtype([("bmin", "<f8", 3), ("bmax", "<f8", 3), ("first", "<u8"), ("count", "<u8")])
+        return {
+            "vertices": np.ctypeslib.as_array(d.vertices, (n, 9)).copy(),
+            "normals": np.ctypeslib.as_array(d.normals, (n, 3)).copy(),
+            "colors": np.ctypeslib.as_array(d.colors, (n, 3)).copy(),
+            "specularity": np.ctypeslib.as_array(d.specularity, (n,)).copy(),
+            "reflectivity": np.ctypeslib.as_array(d.reflectivity, (n,)).copy(),
+            "nodes": np.frombuffer(C.string_at(d.nodes, m * 64), dtype=node_dt).copy(),
+            "indices": np.ctypeslib.as_array(d.indices, (n,)).copy(),
+            "camera_position": np.array(d.camera_position[:]),
+            "camera_rotation_deg": np.array(d.camera_rotation_deg[:]),
+        }
+
+    def set_camera(self, position, rotation_deg) -> None:
+        pos = (C.c_double * 3)(*position)
+        rot = (C.c_double * 3)(*rotation_deg)
+        _check(lib().rtx_host_scene_set_camera(self._h, pos, rot))
+
+    def close(self) -> None:
+        if self._h:
+            lib().rtx_host_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+@dataclass
+class Frame:
+    rgb: np.ndarray            # (H, W, 3) uint8
+    hit: np.ndarray | None     # (H, W) int32 primary triangle ids, -1 = background
+    stats: Stats | None
+
+
+class Scene:
+    """A scene resident in one GPU's HBM."""
+
+    def __init__(self, host: HostScene, device: int = -1):
+        h = C.c_void_p()
+        _check(lib().rtx_scene_create_from_host(host._h, device, C.byref(h)))
+        self._h = h
+
+    @property
+    def device_bytes(self) -> int:
+        return int(lib().rtx_scene_device_bytes(self._h))
+
+    def render(self, width: int, height: int, *, want_hit: bool = True, want_stats: bool = False, **kw) -> Frame:
+        """One frame into host arrays through rtx_render()."""
+        p = make_params(width, height, **kw)
+        px = int(lib().rtx_output_pixels(C.byref(p)))
+        packed = p.layout == LAYOUT_PACKED_TILES
+        rgb = np.zeros((px, 3), dtype=np.uint8)
+        hit = np.full(px, -1, dtype=np.int32) if (want_hit and not packed) else None
+        st = Stats() if want_stats else None
+        _check(lib().rtx_render(self._h, C.byref(p), rgb.ctypes.data, hit.ctypes.data if hit is not None else None,
+                                C.byref(st) if st is not None else None))
+        if not packed:
+            rgb = rgb.reshape(height, width, 3)
+            if hit is not None:
+                hit = hit.reshape(height, width)
+        return Frame(rgb, hit, st)
+
+    def render_device(self, params: RenderParams, *, rgb_u8=0, hit=0, rgb_i32=0, t=0, stats=0, stream=0) -> None:
+        """Asynchronous frame into device pointers (ints, e.g. torch.Tensor.data_ptr())."""
+        _check(lib().rtx_render_device(self._h, C.byref(params), rgb_u8 or None, hit or None, rgb_i32 or None, t or None,
+                                       stats or None, stream or None))
+
+    def close(self) -> None:
+        if self._h:
+            lib().rtx_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def untile(params: RenderParams, n_ranks: int, gathered_ptr: int, out_ptr: int, bytes_per_pixel: int = 3, stream: int = 0):
+    _check(lib().rtx_untile(C.byref(params), n_ranks, gathered_ptr, out_ptr, bytes_per_pixel, stream or None))
+
+
+def save_ppm(path: str, rgb: np.ndarray) -> None:
+    """saveCanvas (src/main.cpp:96-116)."""
+    a = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w = a.shape[:2]
+    _check(lib().rtx_save_ppm(os.fsencode(path), w, h, a.ctypes.data))

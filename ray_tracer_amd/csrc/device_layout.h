@@ -1,0 +1,88 @@
+// Scene layout in HBM and the kernel argument blocks, shared by the host code that
+// flattens a scene (rtx_api.cpp) and the kernels (rtx_kernels.hip).
+//
+// Derived from the reference's BVHNode (include/bvh.hpp:25-30), Triangle
+// (include/triangle.hpp:8-15) and BVH::indices (include/bvh.hpp:34):
+//
+//  * nodes: 64-byte records.  Device slot = reference node index + 1, so the root
+//    is slot 1 and every sibling pair (the reference allocates children as
+//    nodesUsed++, nodesUsed++; bvh.hpp:148-149) sits at slots (2k, 2k+1), i.e. in one
+//    128-byte line.  Slot 0 is unused.
+//  * triangles: 128-byte records stored in BVH::indices order, so a leaf's triangles
+//    are contiguous and `first` of a leaf addresses this array directly.  Each record
+//    carries the original triangle index (what the reference reports as the hit id)
+//    and its leaf's `first`, which decides equal-t ties between leaves.
+//  * materials: 32-byte records in the same order.
+#ifndef RTX_DEVICE_LAYOUT_H
+#define RTX_DEVICE_LAYOUT_H
+
+#include <stdint.h>
+
+namespace rtx {
+
+struct alignas(64) DevNode {
+    double bmin[3];
+    double bmax[3];
+    uint32_t first;   // inner: slot of the left child (right = first + 1); leaf: first triangle position
+    uint32_t count;   // 0 = inner
+    uint32_t pad[2];
+};
+static_assert(sizeof(DevNode) == 64, "DevNode");
+
+struct alignas(128) DevTri {
+    double v0[3], v1[3], v2[3];
+    double n[3];       // Triangle::normal, computed on the host (triangle.hpp:21-23)
+    double d;          // -(n . v0), the per-call constant of triangle.hpp:39
+    uint32_t orig_id;  // index into the reference's Scene::triangles
+    uint32_t leaf_first;
+    double pad[2];
+};
+static_assert(sizeof(DevTri) == 128, "DevTri");
+
+struct alignas(32) DevMat {
+    int32_t color[3];
+    int32_t specularity;
+    double reflectivity;
+    double pad;
+};
+static_assert(sizeof(DevMat) == 32, "DevMat");
+
+struct alignas(32) DevLight {
+    double intensity;
+    double v[3];
+};
+
+struct DevScene {
+    const DevNode *nodes;
+    const DevTri *tris;
+    const DevMat *mats;
+    const DevLight *lights;   // point lights first, then directional
+    uint32_t n_nodes, n_tris, n_point, n_dir;
+    double cam[3];
+    double viewport[3];
+    // cos/sin of the three camera rotations, evaluated on the host with libm exactly
+    // as Vector3::rotateX/Y/Z do per pixel (include/vector3.hpp:54-82)
+    double cx, sx, cy, sy, cz, sz;
+    double ambient;
+    double scene_scale;       // largest |coordinate| of the root box
+    int32_t bg[3];
+    int32_t bvh_depth;
+};
+
+struct DevRender {
+    int32_t W, H, x0, x1, y0, y1;
+    int32_t depth, spp;
+    uint64_t seed;
+    int32_t tile_w, tile_h, tile_rank, tile_count;
+    int32_t tiles_x, tiles_y, owned_tiles, layout;
+    double px, py;            // viewport.x / W, viewport.y / H  (scene.hpp:83-84)
+    uint8_t *rgb;
+    int32_t *hit;
+    int32_t *rgb_i32;
+    double *t;
+    unsigned long long *stats; // 9 counters, rtx_stats order
+    uint32_t stack_stride;     // LDS stack entries per level (= block size)
+};
+
+}  // namespace rtx
+#endif

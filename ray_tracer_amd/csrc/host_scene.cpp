@@ -1,0 +1,367 @@
+// Host scene: OBJ loader, scene factories, triangle setup and the BVH builder.
+// Citations are file:line in khaganmv/ray-tracer.
+#include "host_scene.hpp"
+
+#include <cctype>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+
+namespace rtx {
+
+namespace {
+
+const double kInf = std::numeric_limits<double>::infinity();
+
+bool slurp(const std::string &path, std::string *out) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (sz < 0) { fclose(f); return false; }
+    out->resize(static_cast<size_t>(sz));
+    size_t got = sz ? fread(&(*out)[0], 1, static_cast<size_t>(sz), f) : 0;
+    fclose(f);
+    return got == static_cast<size_t>(sz);
+}
+
+}  // namespace
+
+// Scene::parseOBJ, include/scene.hpp:213-253.
+//
+// The reference tokenises with `fs >> id` (one non-blank char), then `fs >> x >> y >> z`
+// for 'v' or `fs >> i >> j >> k` for 'f'; any other char is dropped.  Its loop
+// condition is `!fs.eof()`, so a file that ends in white space runs the body once
+// more with every extraction failing and the locals still holding the previous
+// record: the last record is pushed twice (teapot.obj plus a newline loads 6331
+// triangles with the reference as built from source).  Kept here, because the scene
+// factories address materials relative to the END of the triangle list.
+// A 'v' or 'f' followed by something that is not three numbers leaves the
+// reference's stream failed and its loop spinning; here that is an error.
+int parse_obj(const std::string &path, std::vector<double> *vertices9, std::string *err) {
+    std::string text;
+    if (!slurp(path, &text)) { *err = "Failed to open file.\n"; return RTX_ERR_IO; }
+    std::vector<double> pos;               // 3 per vertex
+    vertices9->clear();
+    const char *p = text.c_str();
+    const char *const end = p + text.size();
+    char id = 0;
+    double xyz[3] = {0, 0, 0};
+    long long ijk[3] = {0, 0, 0};
+    for (bool done = false; !done;) {
+        while (p < end && isspace(static_cast<unsigned char>(*p))) p++;
+        const bool fresh = p < end;        // false: ran into end-of-file, locals are stale
+        if (fresh) id = *p++;
+        else done = true;
+        if (id == 'v') {
+            if (fresh) {
+                for (double &c : xyz) {
+                    char *q = nullptr;
+                    c = strtod(p, &q);
+                    if (q == p) { *err = "OBJ: vertex record is not 'v x y z'"; return RTX_ERR_UNSUPPORTED; }
+                    p = q;
+                }
+                if (p >= end) done = true; // last number touched end-of-file: eofbit set
+            }
+            pos.insert(pos.end(), xyz, xyz + 3);
+        } else if (id == 'f') {
+            if (fresh) {
+                for (long long &c : ijk) {
+                    char *q = nullptr;
+                    c = strtoll(p, &q, 10);
+                    if (q == p) { *err = "OBJ: face record is not 'f i j k' (run tools/denormalize first)"; return RTX_ERR_UNSUPPORTED; }
+                    p = q;
+                }
+                if (p >= end) done = true;
+            }
+            for (long long c : ijk) {
+                // the reference indexes vertices[c - 1] unchecked (scene.hpp:237-239)
+                if (c < 1 || static_cast<uint64_t>(c) * 3 > pos.size()) {
+                    *err = "OBJ: face references a vertex that is not defined yet";
+                    return RTX_ERR_INVALID;
+                }
+                const double *v = &pos[static_cast<size_t>(c - 1) * 3];
+                vertices9->insert(vertices9->end(), v, v + 3);
+            }
+        }
+    }
+    return RTX_OK;
+}
+
+// Triangle::Triangle, include/triangle.hpp:16-25.
+void setup_triangles(HostScene *hs, bool have_normals) {
+    const uint64_t n = hs->n_triangles();
+    if (!have_normals) hs->normals.resize(3 * n);
+    hs->centroids.resize(3 * n);
+    for (uint64_t i = 0; i < n; i++) {
+        const double *v = &hs->vertices[9 * i];
+        if (!have_normals) {
+            double ax = v[3] - v[0], ay = v[4] - v[1], az = v[5] - v[2];      // e01
+            double bx = v[6] - v[0], by = v[7] - v[1], bz = v[8] - v[2];      // e02
+            double cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+            double len = std::sqrt(cx * cx + cy * cy + cz * cz);
+            hs->normals[3 * i] = cx / len;
+            hs->normals[3 * i + 1] = cy / len;
+            hs->normals[3 * i + 2] = cz / len;
+        }
+        for (int k = 0; k < 3; k++) hs->centroids[3 * i + k] = ((v[k] + v[3 + k]) + v[6 + k]) / 3;
+    }
+}
+
+// The five factories, include/scene.hpp:255-448: they differ only in the file name
+// and the camera position.
+int apply_preset(HostScene *hs, const std::string &preset, std::string *err) {
+    struct P { const char *name; double cam[3]; };
+    static const P table[] = {
+        {"teapot", {-0.015, 4, -11.99}},           // scene.hpp:259
+        {"bunny", {0.1425, 2, -5.94}},             // scene.hpp:298
+        {"erato", {-0.8, 28.7, -86.1}},            // scene.hpp:337
+        {"dragon", {-0.0425, 0.7115, -3.01725}},   // scene.hpp:376
+        {"aurelius", {-0.025, 3.05, -20.9}},       // scene.hpp:415
+    };
+    const P *p = nullptr;
+    for (const P &e : table) if (preset == e.name) p = &e;
+    if (!p) { *err = "unknown scene preset '" + preset + "'"; return RTX_ERR_INVALID; }
+    const uint64_t n = hs->vertices.size() / 9;
+    if (n < 10) {
+        // the reference's `size() - 10` wraps around for such a scene
+        *err = "scene presets need at least the 10 box triangles";
+        return RTX_ERR_INVALID;
+    }
+    for (int k = 0; k < 3; k++) {
+        hs->viewport[k] = 1;
+        hs->camera_position[k] = p->cam[k];
+        hs->background[k] = 255;
+    }
+    hs->camera_rotation_deg[0] = 0; hs->camera_rotation_deg[1] = 0.1; hs->camera_rotation_deg[2] = 0;
+    hs->ambient = 0.2;
+    hs->point_lights.clear();
+    hs->directional_lights.assign(1, rtx_light{0.5, {0, 1, -1}});
+    // parseOBJ materials (scene.hpp:240-242), then the overrides (scene.hpp:273-289)
+    hs->colors.assign(3 * n, 255);
+    hs->specularity.assign(n, 1);
+    hs->reflectivity.assign(n, 0.2);
+    for (uint64_t i = n - 10; i < n; i++) hs->reflectivity[i] = 0.4;
+    for (uint64_t i = n - 4; i < n - 2; i++) { hs->colors[3 * i] = 0; hs->colors[3 * i + 2] = 0; }      // green
+    for (uint64_t i = n - 2; i < n; i++) { hs->colors[3 * i + 1] = 0; hs->colors[3 * i + 2] = 0; }      // red
+    return RTX_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// BVH::BVH / updateNodeBounds / subdivide / findBestSplitPlane,
+// include/bvh.hpp:84-162,236-305, with the recursion replaced by an explicit
+// work stack.  Children are allocated pairwise (left = nodesUsed++, right =
+// nodesUsed++) when their parent is split and the left subtree is finished before
+// the right one is started, so node numbering equals the reference's.
+namespace {
+
+struct Builder {
+    HostScene &s;
+    const double *V;   // vertices
+    const double *C;   // centroids
+    explicit Builder(HostScene &hs) : s(hs), V(hs.vertices.data()), C(hs.centroids.data()) {}
+
+    // Vector3::min/max (include/vector3.hpp:92-106): keeps `a` unless b is strictly better
+    static void grow_point(double lo[3], double hi[3], const double *p) {
+        for (int k = 0; k < 3; k++) {
+            lo[k] = (lo[k] < p[k]) ? lo[k] : p[k];
+            hi[k] = (hi[k] > p[k]) ? hi[k] : p[k];
+        }
+    }
+    // AABB::area (bvh.hpp:74-78)
+    static double half_area(const double lo[3], const double hi[3]) {
+        double ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+        return ex * ey + ey * ez + ez * ex;
+    }
+
+    void bounds(uint64_t node) {                                        // bvh.hpp:100-115
+        rtx_bvh_node &n = s.nodes[node];
+        double lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf};
+        // the reference takes min over v0,v1,v2 and then max over v0,v1,v2 per
+        // triangle; min and max are independent, so one pass per vertex is the same
+        for (uint64_t i = 0; i < n.count; i++) {
+            const double *v = V + 9 * s.indices[n.first + i];
+            grow_point(lo, hi, v);
+            grow_point(lo, hi, v + 3);
+            grow_point(lo, hi, v + 6);
+        }
+        for (int k = 0; k < 3; k++) { n.bmin[k] = lo[k]; n.bmax[k] = hi[k]; }
+    }
+
+    double best_plane(const rtx_bvh_node &n, int *axis_out, double *pos_out) const {   // bvh.hpp:236-305
+        constexpr int kBins = 8;
+        double best = kInf;
+        for (int axis = 0; axis < 3; axis++) {
+            double cmin = kInf, cmax = -kInf;
+            for (uint64_t i = 0; i < n.count; i++) {
+                double c = C[3 * s.indices[n.first + i] + axis];
+                cmin = (c < cmin) ? c : cmin;                            // std::min(cmin, c)
+                cmax = (cmax < c) ? c : cmax;                            // std::max(cmax, c)
+            }
+            if (cmin == cmax) continue;
+            double blo[kBins][3], bhi[kBins][3];
+            int bcount[kBins];
+            for (int b = 0; b < kBins; b++) {
+                bcount[b] = 0;
+                for (int k = 0; k < 3; k++) { blo[b][k] = kInf; bhi[b][k] = -kInf; }
+            }
+            const double scale = kBins / (cmax - cmin);
+            for (uint64_t i = 0; i < n.count; i++) {
+                const uint64_t t = s.indices[n.first + i];
+                size_t b = static_cast<size_t>((C[3 * t + axis] - cmin) * scale);
+                if (b > kBins - 1) b = kBins - 1;
+                bcount[b]++;
+                grow_point(blo[b], bhi[b], V + 9 * t);
+                grow_point(blo[b], bhi[b], V + 9 * t + 3);
+                grow_point(blo[b], bhi[b], V + 9 * t + 6);
+            }
+            // prefix boxes from the left and from the right; AABB::grow(AABB) skips a
+            // box whose bMin.x is still +inf (bvh.hpp:67-72)
+            double larea[kBins - 1], rarea[kBins - 1];
+            int lcount[kBins - 1], rcount[kBins - 1];
+            double llo[3] = {kInf, kInf, kInf}, lhi[3] = {-kInf, -kInf, -kInf};
+            double rlo[3] = {kInf, kInf, kInf}, rhi[3] = {-kInf, -kInf, -kInf};
+            int lsum = 0, rsum = 0;
+            for (int i = 0; i < kBins - 1; i++) {
+                lsum += bcount[i];
+                lcount[i] = lsum;
+                if (blo[i][0] != kInf) { grow_point(llo, lhi, blo[i]); grow_point(llo, lhi, bhi[i]); }
+                larea[i] = half_area(llo, lhi);
+                const int rb = kBins - 1 - i;
+                rsum += bcount[rb];
+                rcount[kBins - 2 - i] = rsum;
+                if (blo[rb][0] != kInf) { grow_point(rlo, rhi, blo[rb]); grow_point(rlo, rhi, bhi[rb]); }
+                rarea[kBins - 2 - i] = half_area(rlo, rhi);
+            }
+            const double width = (cmax - cmin) / kBins;
+            for (int i = 0; i < kBins - 1; i++) {
+                // empty side: 0 * (+inf area) = NaN, and NaN < best is false
+                const double cost = lcount[i] * larea[i] + rcount[i] * rarea[i];
+                if (cost < best) {
+                    best = cost;
+                    *axis_out = axis;
+                    *pos_out = cmin + width * static_cast<double>(i + 1);
+                }
+            }
+        }
+        return best;
+    }
+
+    int run(std::string *err) {
+        const uint64_t n = s.n_triangles();
+        if (n == 0) { *err = "cannot build a BVH over zero triangles"; return RTX_ERR_INVALID; }
+        if (n > 0x7fffffffull) { *err = "more than 2^31-1 triangles"; return RTX_ERR_UNSUPPORTED; }
+        s.indices.resize(n);
+        for (uint64_t i = 0; i < n; i++) s.indices[i] = i;
+        s.nodes.assign(2 * n - 1, rtx_bvh_node{{0, 0, 0}, {0, 0, 0}, 0, 0});
+        s.nodes[0].first = 0;
+        s.nodes[0].count = n;
+        uint64_t used = 1;
+        bounds(0);
+        struct Item { uint64_t node; int32_t depth; };
+        std::vector<Item> todo{{0, 0}};
+        int32_t deepest = 0;
+        while (!todo.empty()) {
+            const Item it = todo.back();
+            todo.pop_back();
+            if (it.depth > deepest) deepest = it.depth;
+            rtx_bvh_node &node = s.nodes[it.node];
+            int axis = 0;
+            double pos = 0;
+            const double best = best_plane(node, &axis, &pos);
+            // BVHNode::cost (bvh.hpp:80-82)
+            if (best >= static_cast<double>(node.count) * half_area(node.bmin, node.bmax)) continue;
+            // in-place partition, bvh.hpp:128-140 (ints in the reference)
+            int64_t i = static_cast<int64_t>(node.first);
+            int64_t j = i + static_cast<int64_t>(node.count) - 1;
+            while (i <= j) {
+                if (C[3 * s.indices[i] + axis] < pos) {
+                    i++;
+                } else {
+                    const uint64_t keep = s.indices[j];
+                    s.indices[j] = s.indices[i];
+                    s.indices[i] = keep;
+                    j--;
+                }
+            }
+            const uint64_t left_n = static_cast<uint64_t>(i) - node.first;
+            if (left_n == 0 || left_n == node.count) continue;
+            const uint64_t l = used++, r = used++;
+            s.nodes[l].first = node.first;
+            s.nodes[l].count = left_n;
+            s.nodes[r].first = static_cast<uint64_t>(i);
+            s.nodes[r].count = node.count - left_n;
+            node.first = l;
+            node.count = 0;
+            bounds(l);
+            bounds(r);
+            todo.push_back({r, it.depth + 1});   // popped after the whole left subtree
+            todo.push_back({l, it.depth + 1});
+        }
+        s.nodes.resize(used);
+        s.bvh_depth = deepest;
+        return RTX_OK;
+    }
+};
+
+}  // namespace
+
+int build_bvh(HostScene *hs, std::string *err) {
+    auto t0 = std::chrono::high_resolution_clock::now();
+    Builder b(*hs);
+    int rc = b.run(err);
+    auto t1 = std::chrono::high_resolution_clock::now();
+    hs->bvh_seconds = std::chrono::duration<double>(t1 - t0).count();
+    return rc;
+}
+
+int32_t measure_bvh_depth(const std::vector<rtx_bvh_node> &nodes) {
+    if (nodes.empty()) return 0;
+    struct Item { uint64_t node; int32_t depth; };
+    std::vector<Item> todo{{0, 0}};
+    int32_t deepest = 0;
+    while (!todo.empty()) {
+        Item it = todo.back();
+        todo.pop_back();
+        if (it.depth > deepest) deepest = it.depth;
+        const rtx_bvh_node &n = nodes[it.node];
+        if (n.count == 0) {
+            todo.push_back({n.first, it.depth + 1});
+            todo.push_back({n.first + 1, it.depth + 1});
+        }
+    }
+    return deepest;
+}
+
+// A caller-supplied tree is walked once before any kernel may index with it: child
+// and triangle ranges in bounds, every node reached at most once (so the walk
+// terminates), every index a valid triangle.
+int validate_bvh(const HostScene &hs, std::string *err) {
+    const uint64_t n = hs.n_triangles(), m = hs.nodes.size();
+    if (m == 0 || hs.indices.size() != n) { *err = "BVH: node or index array has the wrong size"; return RTX_ERR_INVALID; }
+    for (uint64_t t : hs.indices) if (t >= n) { *err = "BVH: triangle index out of range"; return RTX_ERR_INVALID; }
+    std::vector<uint8_t> seen(m, 0);
+    std::vector<uint64_t> todo{0};
+    while (!todo.empty()) {
+        uint64_t k = todo.back();
+        todo.pop_back();
+        if (seen[k]) { *err = "BVH: a node is reachable twice"; return RTX_ERR_INVALID; }
+        seen[k] = 1;
+        const rtx_bvh_node &nd = hs.nodes[k];
+        if (nd.count == 0) {
+            if (nd.first == 0 || nd.first + 1 >= m) { *err = "BVH: child index out of range"; return RTX_ERR_INVALID; }
+            todo.push_back(nd.first);
+            todo.push_back(nd.first + 1);
+        } else if (nd.first > n || nd.count > n - nd.first) {
+            *err = "BVH: leaf range out of range";
+            return RTX_ERR_INVALID;
+        }
+    }
+    return RTX_OK;
+}
+
+}  // namespace rtx

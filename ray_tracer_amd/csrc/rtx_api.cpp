@@ -1,0 +1,498 @@
+// The C ABI declared in include/rtx.h: host scenes, flattening to the device layout,
+// render launches, tile re-assembly and PPM output.
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "device_layout.h"
+#include "host_scene.hpp"
+#include "rtx.h"
+#include "rtx_kernels.h"
+
+static_assert(RTX_LAYOUT_PACKED_TILES == rtx::RTX_LAYOUT_PACKED_TILES_, "layout constant");
+static_assert(sizeof(rtx_bvh_node) == 64, "rtx_bvh_node must match the reference's BVHNode");
+
+struct rtx_host_scene {
+    rtx::HostScene s;
+};
+
+struct rtx_scene {
+    int device = 0;
+    rtx::DevScene dev{};
+    void *d_nodes = nullptr, *d_tris = nullptr, *d_mats = nullptr, *d_lights = nullptr;
+    uint64_t bytes = 0;
+    uint64_t n_triangles = 0;
+    std::mutex lock;
+};
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string &msg) {
+    g_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(RTX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// Selects a device for the current scope and puts the previous one back.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (dev != prev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+int finish_host_scene(rtx_host_scene *hs, bool have_normals, bool have_bvh, int verbose) {
+    rtx::HostScene &s = hs->s;
+    rtx::setup_triangles(&s, have_normals);
+    std::string err;
+    if (have_bvh) {
+        if (int rc = rtx::validate_bvh(s, &err)) return fail(rc, err);
+        s.bvh_depth = rtx::measure_bvh_depth(s.nodes);
+    } else {
+        if (int rc = rtx::build_bvh(&s, &err)) return fail(rc, err);
+        // Scene::Scene prints the build time in seconds (scene.hpp:49-51)
+        if (verbose) printf("[ BVH ] %g seconds.\n", std::floor(s.bvh_seconds * 1000.0) / 1000.0);
+    }
+    return RTX_OK;
+}
+
+struct ResolvedParams {
+    rtx::DevRender r{};
+};
+
+int resolve_params(const rtx_render_params *p, ResolvedParams *out) {
+    if (!p) return fail(RTX_ERR_INVALID, "render params are NULL");
+    if (p->width < 0 || p->height < 0) return fail(RTX_ERR_INVALID, "negative canvas size");
+    if ((int64_t)p->width * p->height > (int64_t)1 << 31) return fail(RTX_ERR_UNSUPPORTED, "canvas larger than 2^31 pixels");
+    if (p->depth < 0 || p->depth > 7) return fail(RTX_ERR_INVALID, "depth must be 0..7");
+    if (p->spp < 1 || p->spp > 4096) return fail(RTX_ERR_INVALID, "spp must be 1..4096");
+    if (p->traversal != RTX_TRAVERSAL_REFERENCE && p->traversal != RTX_TRAVERSAL_PRUNED) return fail(RTX_ERR_INVALID, "unknown traversal mode");
+    if (p->layout != RTX_LAYOUT_ROW_MAJOR && p->layout != RTX_LAYOUT_PACKED_TILES) return fail(RTX_ERR_INVALID, "unknown layout");
+    rtx::DevRender &r = out->r;
+    r.W = p->width; r.H = p->height;
+    r.x0 = p->x0; r.x1 = p->x1; r.y0 = p->y0; r.y1 = p->y1;
+    if (r.x0 == 0 && r.x1 == 0 && r.y0 == 0 && r.y1 == 0) { r.x1 = r.W; r.y1 = r.H; }
+    if (r.x0 < 0 || r.y0 < 0 || r.x1 > r.W || r.y1 > r.H || r.x0 > r.x1 || r.y0 > r.y1) return fail(RTX_ERR_INVALID, "pixel window outside the canvas");
+    r.depth = p->depth; r.spp = p->spp; r.seed = p->seed;
+    r.tile_w = p->tile_w > 0 ? p->tile_w : 32;
+    r.tile_h = p->tile_h > 0 ? p->tile_h : 32;
+    if (r.tile_w % 8 || r.tile_h % 8 || r.tile_w > 4096 || r.tile_h > 4096) return fail(RTX_ERR_INVALID, "tile size must be a multiple of 8, at most 4096");
+    r.tile_count = p->tile_count > 1 ? p->tile_count : 1;
+    r.tile_rank = r.tile_count > 1 ? p->tile_rank : 0;
+    if (r.tile_rank < 0 || r.tile_rank >= r.tile_count) return fail(RTX_ERR_INVALID, "tile_rank outside [0, tile_count)");
+    r.tiles_x = (r.W + r.tile_w - 1) / r.tile_w;
+    r.tiles_y = (r.H + r.tile_h - 1) / r.tile_h;
+    const int64_t tiles = (int64_t)r.tiles_x * r.tiles_y;
+    // tiles k = rank, rank + count, ...
+    r.owned_tiles = tiles > r.tile_rank ? (int32_t)((tiles - r.tile_rank + r.tile_count - 1) / r.tile_count) : 0;
+    r.layout = p->layout;
+    return RTX_OK;
+}
+
+// Equal for every rank, so that the gathered buffer is [rank][max_owned][tile_h][tile_w].
+uint64_t packed_tiles_per_rank(const rtx::DevRender &r) {
+    const int64_t tiles = (int64_t)r.tiles_x * r.tiles_y;
+    return (uint64_t)((tiles + r.tile_count - 1) / r.tile_count);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rtx_last_error(void) { return g_error.c_str(); }
+const char *rtx_version(void) { return "rtx-mi355x 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------ host scenes
+int rtx_host_scene_load_obj(const char *obj_path, const char *preset, int verbose, rtx_host_scene **out) {
+    if (!obj_path || !preset || !out) return fail(RTX_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    rtx_host_scene *hs = new (std::nothrow) rtx_host_scene;
+    if (!hs) return fail(RTX_ERR_NOMEM, "out of host memory");
+    std::string err;
+    int rc = rtx::parse_obj(obj_path, &hs->s.vertices, &err);
+    // Scene::parseOBJ prints the face count (scene.hpp:248)
+    if (rc == RTX_OK && verbose) printf("[ TRI ] %zu triangles.\n", hs->s.vertices.size() / 9);
+    if (rc == RTX_OK) rc = rtx::apply_preset(&hs->s, preset, &err);
+    if (rc != RTX_OK) { delete hs; return fail(rc, err); }
+    rc = finish_host_scene(hs, false, false, verbose);
+    if (rc != RTX_OK) { delete hs; return rc; }
+    *out = hs;
+    return RTX_OK;
+}
+
+int rtx_host_scene_standin(const char *preset, uint64_t n_triangles, uint64_t seed, const char *obj_path_out, int verbose,
+                           rtx_host_scene **out) {
+    if (!preset) return fail(RTX_ERR_INVALID, "NULL preset");
+    if (out) *out = nullptr;
+    std::vector<double> verts;
+    std::vector<uint32_t> faces;
+    std::string err;
+    if (int rc = rtx::generate_standin(preset, n_triangles, seed, &verts, &faces, &err)) return fail(rc, err);
+    if (obj_path_out)
+        if (int rc = rtx::write_obj(obj_path_out, verts, faces, &err)) return fail(rc, err);
+    if (!out) return RTX_OK;
+    rtx_host_scene *hs = new (std::nothrow) rtx_host_scene;
+    if (!hs) return fail(RTX_ERR_NOMEM, "out of host memory");
+    hs->s.vertices.reserve(faces.size() * 3);
+    for (uint32_t v : faces) hs->s.vertices.insert(hs->s.vertices.end(), &verts[3 * (size_t)v], &verts[3 * (size_t)v] + 3);
+    if (verbose) printf("[ TRI ] %zu triangles.\n", hs->s.vertices.size() / 9);
+    int rc = rtx::apply_preset(&hs->s, preset, &err);
+    if (rc != RTX_OK) { delete hs; return fail(rc, err); }
+    rc = finish_host_scene(hs, false, false, verbose);
+    if (rc != RTX_OK) { delete hs; return rc; }
+    *out = hs;
+    return RTX_OK;
+}
+
+int rtx_host_scene_from_desc(const rtx_scene_desc *d, rtx_host_scene **out) {
+    if (!d || !out) return fail(RTX_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    const uint64_t n = d->n_triangles;
+    if (n == 0) return fail(RTX_ERR_INVALID, "scene has no triangles");
+    if (n > 0x7fffffffull) return fail(RTX_ERR_UNSUPPORTED, "more than 2^31-1 triangles");
+    if (!d->vertices || !d->colors || !d->specularity || !d->reflectivity) return fail(RTX_ERR_INVALID, "triangle arrays missing");
+    if ((d->n_point_lights && !d->point_lights) || (d->n_directional_lights && !d->directional_lights)) return fail(RTX_ERR_INVALID, "light arrays missing");
+    const bool have_bvh = d->n_nodes != 0 || d->nodes || d->indices;
+    if (have_bvh && (!d->nodes || !d->indices || d->n_nodes == 0 || d->n_nodes > 2 * n - 1)) return fail(RTX_ERR_INVALID, "BVH arrays incomplete");
+    rtx_host_scene *hs = new (std::nothrow) rtx_host_scene;
+    if (!hs) return fail(RTX_ERR_NOMEM, "out of host memory");
+    rtx::HostScene &s = hs->s;
+    s.vertices.assign(d->vertices, d->vertices + 9 * n);
+    if (d->normals) s.normals.assign(d->normals, d->normals + 3 * n);
+    s.colors.assign(d->colors, d->colors + 3 * n);
+    s.specularity.assign(d->specularity, d->specularity + n);
+    s.reflectivity.assign(d->reflectivity, d->reflectivity + n);
+    if (have_bvh) {
+        s.nodes.assign(d->nodes, d->nodes + d->n_nodes);
+        s.indices.assign(d->indices, d->indices + n);
+    }
+    for (int k = 0; k < 3; k++) {
+        s.viewport[k] = d->viewport[k];
+        s.camera_position[k] = d->camera_position[k];
+        s.camera_rotation_deg[k] = d->camera_rotation_deg[k];
+        s.background[k] = d->background[k];
+    }
+    s.ambient = d->ambient;
+    s.point_lights.assign(d->point_lights, d->point_lights + d->n_point_lights);
+    s.directional_lights.assign(d->directional_lights, d->directional_lights + d->n_directional_lights);
+    int rc = finish_host_scene(hs, d->normals != nullptr, have_bvh, 0);
+    if (rc != RTX_OK) { delete hs; return rc; }
+    *out = hs;
+    return RTX_OK;
+}
+
+int rtx_host_scene_desc(const rtx_host_scene *hs, rtx_scene_desc *o) {
+    if (!hs || !o) return fail(RTX_ERR_INVALID, "NULL argument");
+    const rtx::HostScene &s = hs->s;
+    memset(o, 0, sizeof *o);
+    o->n_triangles = s.n_triangles();
+    o->vertices = s.vertices.data();
+    o->normals = s.normals.data();
+    o->colors = s.colors.data();
+    o->specularity = s.specularity.data();
+    o->reflectivity = s.reflectivity.data();
+    o->n_nodes = s.nodes.size();
+    o->nodes = s.nodes.data();
+    o->indices = s.indices.data();
+    for (int k = 0; k < 3; k++) {
+        o->viewport[k] = s.viewport[k];
+        o->camera_position[k] = s.camera_position[k];
+        o->camera_rotation_deg[k] = s.camera_rotation_deg[k];
+        o->background[k] = s.background[k];
+    }
+    o->ambient = s.ambient;
+    o->n_point_lights = (uint32_t)s.point_lights.size();
+    o->point_lights = s.point_lights.data();
+    o->n_directional_lights = (uint32_t)s.directional_lights.size();
+    o->directional_lights = s.directional_lights.data();
+    o->device = -1;
+    return RTX_OK;
+}
+
+int32_t rtx_host_scene_bvh_depth(const rtx_host_scene *hs) { return hs ? hs->s.bvh_depth : -1; }
+
+int rtx_host_scene_set_camera(rtx_host_scene *hs, const double position[3], const double rotation_deg[3]) {
+    if (!hs || !position || !rotation_deg) return fail(RTX_ERR_INVALID, "NULL argument");
+    for (int k = 0; k < 3; k++) { hs->s.camera_position[k] = position[k]; hs->s.camera_rotation_deg[k] = rotation_deg[k]; }
+    return RTX_OK;
+}
+
+int rtx_host_scene_set_lights(rtx_host_scene *hs, double ambient, uint32_t n_point, const rtx_light *point,
+                              uint32_t n_directional, const rtx_light *directional) {
+    if (!hs || (n_point && !point) || (n_directional && !directional)) return fail(RTX_ERR_INVALID, "NULL argument");
+    hs->s.ambient = ambient;
+    hs->s.point_lights.assign(point, point + n_point);
+    hs->s.directional_lights.assign(directional, directional + n_directional);
+    return RTX_OK;
+}
+
+void rtx_host_scene_free(rtx_host_scene *hs) { delete hs; }
+
+// ------------------------------------------------------------------ device scenes
+int rtx_scene_create_from_host(const rtx_host_scene *hs, int32_t device, rtx_scene **out) {
+    if (!hs || !out) return fail(RTX_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    const rtx::HostScene &s = hs->s;
+    const uint64_t n = s.n_triangles(), m = s.nodes.size();
+    if (n == 0 || m == 0) return fail(RTX_ERR_INVALID, "scene is empty");
+    if (m + 1 > 0xffffffffull) return fail(RTX_ERR_UNSUPPORTED, "too many BVH nodes");
+
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    if (device >= ndev) return fail(RTX_ERR_INVALID, "device ordinal out of range");
+
+    // nodes: slot = reference index + 1; leaf `first` already addresses the re-ordered
+    // triangle array because that array IS BVH::indices order
+    std::vector<rtx::DevNode> nodes(m + 1);
+    memset(nodes.data(), 0, nodes.size() * sizeof(rtx::DevNode));
+    for (uint64_t i = 0; i < m; i++) {
+        const rtx_bvh_node &h = s.nodes[i];
+        rtx::DevNode &d = nodes[i + 1];
+        for (int k = 0; k < 3; k++) { d.bmin[k] = h.bmin[k]; d.bmax[k] = h.bmax[k]; }
+        d.count = (uint32_t)h.count;
+        d.first = h.count == 0 ? (uint32_t)(h.first + 1) : (uint32_t)h.first;
+    }
+    std::vector<rtx::DevTri> tris(n);
+    std::vector<rtx::DevMat> mats(n);
+    memset(tris.data(), 0, n * sizeof(rtx::DevTri));
+    memset(mats.data(), 0, n * sizeof(rtx::DevMat));
+    for (uint64_t pos = 0; pos < n; pos++) {
+        const uint64_t id = s.indices[pos];
+        rtx::DevTri &t = tris[pos];
+        const double *v = &s.vertices[9 * id];
+        const double *nn = &s.normals[3 * id];
+        for (int k = 0; k < 3; k++) { t.v0[k] = v[k]; t.v1[k] = v[3 + k]; t.v2[k] = v[6 + k]; t.n[k] = nn[k]; }
+        // double d = -normal.dot(v0);  (triangle.hpp:39)
+        t.d = -(nn[0] * v[0] + nn[1] * v[1] + nn[2] * v[2]);
+        t.orig_id = (uint32_t)id;
+        rtx::DevMat &mt = mats[pos];
+        for (int k = 0; k < 3; k++) mt.color[k] = s.colors[3 * id + k];
+        mt.specularity = s.specularity[id];
+        mt.reflectivity = s.reflectivity[id];
+    }
+    for (uint64_t i = 0; i < m; i++) {
+        const rtx_bvh_node &h = s.nodes[i];
+        for (uint64_t j = 0; j < h.count; j++) tris[h.first + j].leaf_first = (uint32_t)h.first;
+    }
+    std::vector<rtx::DevLight> lights;
+    for (const rtx_light &l : s.point_lights) lights.push_back({l.intensity, {l.v[0], l.v[1], l.v[2]}});
+    for (const rtx_light &l : s.directional_lights) lights.push_back({l.intensity, {l.v[0], l.v[1], l.v[2]}});
+
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(RTX_ERR_DEVICE, "cannot select the device");
+    rtx_scene *sc = new (std::nothrow) rtx_scene;
+    if (!sc) return fail(RTX_ERR_NOMEM, "out of host memory");
+    sc->device = device;
+    sc->n_triangles = n;
+    auto upload = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
+        if (e != hipSuccess) return e;
+        sc->bytes += bytes;
+        return bytes ? hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+    };
+    hipError_t e = upload(&sc->d_nodes, nodes.data(), nodes.size() * sizeof(rtx::DevNode));
+    if (e == hipSuccess) e = upload(&sc->d_tris, tris.data(), n * sizeof(rtx::DevTri));
+    if (e == hipSuccess) e = upload(&sc->d_mats, mats.data(), n * sizeof(rtx::DevMat));
+    if (e == hipSuccess) e = upload(&sc->d_lights, lights.data(), lights.size() * sizeof(rtx::DevLight));
+    if (e != hipSuccess) {
+        rtx_scene_destroy(sc);
+        return fail(RTX_ERR_DEVICE, std::string("scene upload: ") + hipGetErrorString(e));
+    }
+    rtx::DevScene &d = sc->dev;
+    d.nodes = (const rtx::DevNode *)sc->d_nodes;
+    d.tris = (const rtx::DevTri *)sc->d_tris;
+    d.mats = (const rtx::DevMat *)sc->d_mats;
+    d.lights = (const rtx::DevLight *)sc->d_lights;
+    d.n_nodes = (uint32_t)(m + 1);
+    d.n_tris = (uint32_t)n;
+    d.n_point = (uint32_t)s.point_lights.size();
+    d.n_dir = (uint32_t)s.directional_lights.size();
+    double scale = 0;
+    for (int k = 0; k < 3; k++) {
+        d.cam[k] = s.camera_position[k];
+        d.viewport[k] = s.viewport[k];
+        d.bg[k] = s.background[k];
+        double a = std::fabs(s.nodes[0].bmin[k]), b = std::fabs(s.nodes[0].bmax[k]);
+        if (a > scale) scale = a;
+        if (b > scale) scale = b;
+    }
+    d.scene_scale = scale;
+    // Vector3::rotateX/Y/Z call cos(radians) and sin(radians) with
+    // radians = (degrees / 180.0) * M_PI (util.hpp:12-14); same libm, same bits
+    const double rx = (s.camera_rotation_deg[0] / 180.0) * M_PI, ry = (s.camera_rotation_deg[1] / 180.0) * M_PI,
+                 rz = (s.camera_rotation_deg[2] / 180.0) * M_PI;
+    d.cx = std::cos(rx); d.sx = std::sin(rx);
+    d.cy = std::cos(ry); d.sy = std::sin(ry);
+    d.cz = std::cos(rz); d.sz = std::sin(rz);
+    d.ambient = s.ambient;
+    d.bvh_depth = s.bvh_depth;
+    *out = sc;
+    return RTX_OK;
+}
+
+int rtx_scene_create(const rtx_scene_desc *desc, rtx_scene **out) {
+    if (!desc || !out) return fail(RTX_ERR_INVALID, "NULL argument");
+    rtx_host_scene *hs = nullptr;
+    if (int rc = rtx_host_scene_from_desc(desc, &hs)) return rc;
+    int rc = rtx_scene_create_from_host(hs, desc->device, out);
+    rtx_host_scene_free(hs);
+    return rc;
+}
+
+void rtx_scene_destroy(rtx_scene *sc) {
+    if (!sc) return;
+    DeviceGuard guard(sc->device);
+    (void)hipFree(sc->d_nodes);
+    (void)hipFree(sc->d_tris);
+    (void)hipFree(sc->d_mats);
+    (void)hipFree(sc->d_lights);
+    delete sc;
+}
+
+uint64_t rtx_scene_device_bytes(const rtx_scene *sc) { return sc ? sc->bytes : 0; }
+
+// ------------------------------------------------------------------ render
+void rtx_render_params_default(rtx_render_params *p, int32_t width, int32_t height) {
+    if (!p) return;
+    memset(p, 0, sizeof *p);
+    p->width = width;
+    p->height = height;
+    p->depth = 3;              // src/main.cpp:83
+    p->spp = 1;
+    p->traversal = RTX_TRAVERSAL_REFERENCE;
+    p->tile_w = 32;
+    p->tile_h = 32;
+    p->tile_count = 1;
+    p->layout = RTX_LAYOUT_ROW_MAJOR;
+}
+
+uint64_t rtx_output_pixels(const rtx_render_params *p) {
+    ResolvedParams rp;
+    if (resolve_params(p, &rp) != RTX_OK) return 0;
+    if (rp.r.layout == RTX_LAYOUT_ROW_MAJOR) return (uint64_t)rp.r.W * (uint64_t)rp.r.H;
+    return packed_tiles_per_rank(rp.r) * (uint64_t)rp.r.tile_w * (uint64_t)rp.r.tile_h;
+}
+
+int rtx_render_device(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id, void *d_rgb_i32, void *d_t,
+                      void *d_stats, void *stream) {
+    if (!sc) return fail(RTX_ERR_INVALID, "scene is NULL");
+    ResolvedParams rp;
+    if (int rc = resolve_params(p, &rp)) return rc;
+    rtx::DevRender &r = rp.r;
+    // what the kernel indexes with must match what it was given
+    if (r.layout == RTX_LAYOUT_PACKED_TILES && (d_hit_id || d_t)) return fail(RTX_ERR_INVALID, "hit ids / t are only written in row-major layout");
+    r.px = sc->dev.viewport[0] / r.W;     // this->viewport.x / canvasWidth  (scene.hpp:83)
+    r.py = sc->dev.viewport[1] / r.H;
+    r.rgb = (uint8_t *)d_rgb_u8;
+    r.hit = (int32_t *)d_hit_id;
+    r.rgb_i32 = (int32_t *)d_rgb_i32;
+    r.t = (double *)d_t;
+    r.stats = (unsigned long long *)d_stats;
+    // LDS stack: the largest block whose stack fits 64 KiB
+    uint32_t block = 256;
+    while (block > 64 && rtx::render_lds_bytes(sc->dev.bvh_depth, r.depth, block) > 65536) block >>= 1;
+    if (rtx::render_lds_bytes(sc->dev.bvh_depth, r.depth, block) > 65536)
+        return fail(RTX_ERR_UNSUPPORTED, "BVH deeper than 255 levels: traversal stack does not fit LDS");
+    r.stack_stride = block;
+    if (r.W == 0 || r.H == 0 || r.owned_tiles == 0) return RTX_OK;
+    DeviceGuard guard(sc->device);
+    if (!guard.ok) return fail(RTX_ERR_DEVICE, "cannot select the scene's device");
+    HIP_TRY(rtx::launch_render(sc->dev, r, p->traversal == RTX_TRAVERSAL_PRUNED, d_stats != nullptr, block, (hipStream_t)stream));
+    return RTX_OK;
+}
+
+int rtx_render(rtx_scene *sc, const rtx_render_params *p, uint8_t *rgb_out, int32_t *hit_id_out, rtx_stats *stats) {
+    if (!sc) return fail(RTX_ERR_INVALID, "scene is NULL");
+    if (!rgb_out) return fail(RTX_ERR_INVALID, "rgb_out is NULL");
+    const uint64_t px = rtx_output_pixels(p);
+    ResolvedParams rp;
+    if (int rc = resolve_params(p, &rp)) return rc;
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (px == 0) return RTX_OK;
+    std::lock_guard<std::mutex> hold(sc->lock);
+    DeviceGuard guard(sc->device);
+    if (!guard.ok) return fail(RTX_ERR_DEVICE, "cannot select the scene's device");
+    void *d_rgb = nullptr, *d_hit = nullptr, *d_stats = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = RTX_OK;
+    auto cleanup = [&]() {
+        (void)hipFree(d_rgb); (void)hipFree(d_hit); (void)hipFree(d_stats);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    };
+#define HIP_TRY_C(expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) { cleanup(); return fail(RTX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
+    } while (0)
+    HIP_TRY_C(hipMalloc(&d_rgb, px * 3));
+    HIP_TRY_C(hipMemset(d_rgb, 0, px * 3));
+    if (hit_id_out) { HIP_TRY_C(hipMalloc(&d_hit, px * 4)); HIP_TRY_C(hipMemset(d_hit, 0xff, px * 4)); }
+    if (stats) { HIP_TRY_C(hipMalloc(&d_stats, 9 * 8)); HIP_TRY_C(hipMemset(d_stats, 0, 9 * 8)); }
+    HIP_TRY_C(hipEventCreate(&e0));
+    HIP_TRY_C(hipEventCreate(&e1));
+    HIP_TRY_C(hipEventRecord(e0, nullptr));
+    rc = rtx_render_device(sc, p, d_rgb, d_hit, nullptr, nullptr, d_stats, nullptr);
+    if (rc != RTX_OK) { cleanup(); return rc; }
+    HIP_TRY_C(hipEventRecord(e1, nullptr));
+    HIP_TRY_C(hipEventSynchronize(e1));
+    HIP_TRY_C(hipMemcpy(rgb_out, d_rgb, px * 3, hipMemcpyDeviceToHost));
+    if (hit_id_out) HIP_TRY_C(hipMemcpy(hit_id_out, d_hit, px * 4, hipMemcpyDeviceToHost));
+    if (stats) {
+        unsigned long long c[9];
+        HIP_TRY_C(hipMemcpy(c, d_stats, sizeof c, hipMemcpyDeviceToHost));
+        stats->primary_rays = c[0]; stats->reflection_rays = c[1]; stats->shadow_rays = c[2];
+        stats->shadow_occluded = c[3]; stats->closest_hits = c[4]; stats->node_visits = c[5];
+        stats->box_hits = c[6]; stats->leaf_visits = c[7]; stats->triangle_tests = c[8];
+        float ms = 0;
+        HIP_TRY_C(hipEventElapsedTime(&ms, e0, e1));
+        stats->kernel_ms = ms;
+    }
+    cleanup();
+    return RTX_OK;
+#undef HIP_TRY_C
+}
+
+int rtx_untile(const rtx_render_params *p, int32_t n_ranks, const void *d_gathered, void *d_out, int32_t bpp, void *stream) {
+    ResolvedParams rp;
+    if (int rc = resolve_params(p, &rp)) return rc;
+    if (!d_gathered || !d_out) return fail(RTX_ERR_INVALID, "NULL buffer");
+    if (n_ranks < 1 || n_ranks != rp.r.tile_count) return fail(RTX_ERR_INVALID, "n_ranks must equal params.tile_count");
+    if (bpp < 1 || bpp > 16) return fail(RTX_ERR_INVALID, "bytes_per_pixel must be 1..16");
+    const uint64_t rank_stride = packed_tiles_per_rank(rp.r) * (uint64_t)rp.r.tile_w * (uint64_t)rp.r.tile_h * (uint64_t)bpp;
+    HIP_TRY(rtx::launch_untile((const uint8_t *)d_gathered, (uint8_t *)d_out, rp.r.W, rp.r.H, rp.r.tile_w, rp.r.tile_h,
+                               rp.r.tiles_x, n_ranks, rank_stride, bpp, (hipStream_t)stream));
+    return RTX_OK;
+}
+
+// saveCanvas, src/main.cpp:96-116 (the clamp already happened on the device)
+int rtx_save_ppm(const char *path, int32_t width, int32_t height, const uint8_t *rgb) {
+    if (!path || !rgb || width < 0 || height < 0) return fail(RTX_ERR_INVALID, "bad argument");
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(RTX_ERR_IO, "Failed to open file.\n");
+    fprintf(f, "P6\n%d %d 255\n", width, height);
+    const size_t n = (size_t)width * (size_t)height * 3;
+    const bool ok = fwrite(rgb, 1, n, f) == n;
+    if (fclose(f) != 0 || !ok) return fail(RTX_ERR_IO, "short write");
+    return RTX_OK;
+}
+
+}  // extern "C"

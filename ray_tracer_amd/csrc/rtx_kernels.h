@@ -1,0 +1,27 @@
+// Launch wrappers of rtx_kernels.hip, called by the C ABI (rtx_api.cpp).
+#ifndef RTX_KERNELS_H
+#define RTX_KERNELS_H
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "device_layout.h"
+
+namespace rtx {
+
+// must equal RTX_LAYOUT_PACKED_TILES in include/rtx.h (checked in rtx_api.cpp)
+constexpr int RTX_LAYOUT_PACKED_TILES_ = 1;
+
+// LDS bytes a render launch needs per block: one u32 traversal-stack slot per tree
+// level per lane, then 5 u32 (localColor r g b + reflectivity) per reflection level per lane.
+inline size_t render_lds_bytes(int32_t bvh_depth, int32_t ray_depth, uint32_t block_threads) {
+    return ((size_t)(bvh_depth + 1) + (size_t)ray_depth * 5) * block_threads * sizeof(uint32_t);
+}
+
+hipError_t launch_render(const DevScene &sc, const DevRender &rp, bool prune, bool stats, uint32_t block_threads,
+                         hipStream_t st);
+hipError_t launch_untile(const uint8_t *src, uint8_t *dst, int W, int H, int tile_w, int tile_h, int tiles_x, int n_ranks,
+                         uint64_t rank_stride, int bpp, hipStream_t st);
+
+}  // namespace rtx
+#endif

@@ -1,0 +1,68 @@
+// Command-line driver: the reference's main() (src/main.cpp:24-73) with the render
+// threads replaced by rtx_render().  Same console lines ("[ TRI ] ...", "[ BVH ] ...",
+// three frame times in seconds with 3 decimals), same P6 output, same error
+// convention (message on stderr, exit code -1).  What the reference fixes at compile
+// time (scene, canvas size, recursion depth; src/main.cpp:8-9,28,83) are flags here.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rtx.h"
+
+int main(int argc, char **argv) {
+    std::string scene = "teapot", obj, out = "out/canvas.ppm", mode = "reference";
+    int width = 1920, height = 1920, depth = 3, spp = 1, repeats = 3, device = -1;
+    unsigned long long standin = 0;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto val = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
+        if (a == "--scene") scene = val();
+        else if (a == "--obj") obj = val();
+        else if (a == "--out") out = val();
+        else if (a == "--mode") mode = val();
+        else if (a == "--width") width = atoi(val());
+        else if (a == "--height") height = atoi(val());
+        else if (a == "--depth") depth = atoi(val());
+        else if (a == "--spp") spp = atoi(val());
+        else if (a == "--repeats") repeats = atoi(val());
+        else if (a == "--device") device = atoi(val());
+        else if (a == "--standin") standin = strtoull(val(), nullptr, 10);
+        else {
+            fprintf(stderr,
+                    "usage: %s [--scene teapot|bunny|erato|dragon|aurelius] [--obj FILE | --standin NTRIS] [--width W] "
+                    "[--height H] [--depth D] [--spp N] [--mode reference|pruned] [--repeats N] [--device K] [--out FILE]\n",
+                    argv[0]);
+            return 2;
+        }
+    }
+    if (obj.empty() && !standin) obj = "scenes/" + scene + ".obj";     // scene.hpp:262
+
+    rtx_host_scene *hs = nullptr;
+    int rc = standin ? rtx_host_scene_standin(scene.c_str(), standin, 0, nullptr, 1, &hs)
+                     : rtx_host_scene_load_obj(obj.c_str(), scene.c_str(), 1, &hs);
+    if (rc != RTX_OK) { fprintf(stderr, "%s", rtx_last_error()); return -1; }
+    rtx_scene *sc = nullptr;
+    if (rtx_scene_create_from_host(hs, device, &sc) != RTX_OK) { fprintf(stderr, "%s\n", rtx_last_error()); return -1; }
+
+    rtx_render_params p;
+    rtx_render_params_default(&p, width, height);
+    p.depth = depth;
+    p.spp = spp;
+    p.traversal = mode == "pruned" ? RTX_TRAVERSAL_PRUNED : RTX_TRAVERSAL_REFERENCE;
+    std::vector<uint8_t> rgb((size_t)width * height * 3);
+    for (int n = 0; n < repeats; n++) {
+        auto t0 = std::chrono::high_resolution_clock::now();
+        if (rtx_render(sc, &p, rgb.data(), nullptr, nullptr) != RTX_OK) { fprintf(stderr, "%s\n", rtx_last_error()); return -1; }
+        auto t1 = std::chrono::high_resolution_clock::now();
+        long long ms = std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count();
+        printf("%.3f ", (double)ms / 1000);                             // src/main.cpp:40,57
+    }
+    printf("\n");
+    if (rtx_save_ppm(out.c_str(), width, height, rgb.data()) != RTX_OK) { fprintf(stderr, "%s", rtx_last_error()); return -1; }
+    rtx_scene_destroy(sc);
+    rtx_host_scene_free(hs);
+    return 0;
+}

@@ -1,0 +1,171 @@
+// Stand-in meshes for the four scenes whose .obj files cannot ship with this
+// repository (bunny 144 056, erato 412 508, dragon 871 316, aurelius 1 704 768
+// faces; include/scene.hpp:294,333,372,411).  A stand-in is a closed, bumpy,
+// star-shaped surface tessellated to exactly n - 10 triangles, standing on the
+// floor of the 10-triangle open box the reference scenes end with
+// (tools/range.py:40-54 gives the box faces; :24-32 the ratio of the mesh's
+// bounding-box volume to the box volume, 27360/216000).
+//
+// Everything is a pure function of (preset, n, seed): integer hashing, IEEE
+// arithmetic and libm sin/cos, then every coordinate is rounded through the
+// "%.9f" text the .obj file carries, so a scene generated in memory equals the
+// scene re-loaded from the written file.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "host_scene.hpp"
+
+namespace rtx {
+
+namespace {
+
+inline uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+inline double unit(uint64_t h) { return static_cast<double>(h >> 11) * (1.0 / 9007199254740992.0); }
+
+inline double through_text(double v) {
+    char buf[64];
+    snprintf(buf, sizeof buf, "%.9f", v);
+    return strtod(buf, nullptr);
+}
+
+}  // namespace
+
+int generate_standin(const std::string &preset, uint64_t n_triangles, uint64_t seed,
+                     std::vector<double> *verts, std::vector<uint32_t> *faces, std::string *err) {
+    HostScene probe;
+    probe.vertices.assign(90, 0.0);
+    if (int rc = apply_preset(&probe, preset, err)) return rc;
+    if (n_triangles < 10 + 8) { *err = "stand-in needs at least 18 triangles"; return RTX_ERR_INVALID; }
+    if ((n_triangles - 10) % 2) { *err = "stand-in triangle count must be even"; return RTX_ERR_INVALID; }
+    const uint64_t target = n_triangles - 10;
+
+    // UV sphere: `cols` meridians, `bands` latitude bands -> 2*cols*(bands-1) triangles,
+    // the remainder made up by splitting triangles at their centroid (+2 each).
+    uint64_t cols = static_cast<uint64_t>(std::sqrt(static_cast<double>(target)));
+    if (cols < 3) cols = 3;
+    uint64_t bands = target / (2 * cols) + 1;
+    if (bands < 2) { bands = 2; cols = target / 2; }
+    while (2 * cols * (bands - 1) > target) bands--;
+    const uint64_t base = 2 * cols * (bands - 1);
+    const uint64_t extra = (target - base) / 2;
+
+    // box: side = 2 * camera height, centred under the camera in x, around z = 0
+    const double side = 2 * probe.camera_position[1];
+    const double cx = probe.camera_position[0];
+    // mesh bounding box as a fraction of the box side: 0.50 * 0.62 * 0.41 = 0.1271
+    const double half_w = 0.25 * side, height = 0.62 * side, half_d = 0.205 * side;
+
+    const double kPi = 3.14159265358979323846;
+    const double ph1 = 2 * kPi * unit(mix64(seed ^ 0x11)), ph2 = 2 * kPi * unit(mix64(seed ^ 0x22)),
+                 ph3 = 2 * kPi * unit(mix64(seed ^ 0x33));
+    auto radius = [&](double theta, double phi, uint64_t vid) {
+        // theta in [0, pi] from the north pole, phi in [0, 2pi)
+        double r = 1.0;
+        r += 0.22 * std::sin(3 * theta + ph1) * std::cos(2 * phi + ph2);
+        r += 0.10 * std::sin(9 * theta + ph2) * std::sin(7 * phi + ph3);
+        r += 0.035 * std::sin(31 * theta + ph3) * std::cos(29 * phi + ph1);
+        r += 0.010 * (unit(mix64(seed * 0x100000001B3ull + vid)) - 0.5);   // scan-like roughness
+        return r;
+    };
+
+    std::vector<double> raw;   // model vertices before fitting
+    raw.reserve(3 * (cols * (bands - 1) + 2 + extra));
+    auto push = [&](double x, double y, double z) { raw.push_back(x); raw.push_back(y); raw.push_back(z); };
+    // vertex 0 = north pole, then (bands-1) rings of `cols`, then the south pole
+    push(0, radius(0, 0, 0), 0);
+    for (uint64_t b = 1; b < bands; b++) {
+        const double theta = kPi * static_cast<double>(b) / static_cast<double>(bands);
+        for (uint64_t c = 0; c < cols; c++) {
+            const double phi = 2 * kPi * static_cast<double>(c) / static_cast<double>(cols);
+            const double r = radius(theta, phi, 1 + (b - 1) * cols + c);
+            push(r * std::sin(theta) * std::cos(phi), r * std::cos(theta), r * std::sin(theta) * std::sin(phi));
+        }
+    }
+    const uint64_t south = 1 + (bands - 1) * cols;
+    push(0, -radius(kPi, 0, south), 0);
+
+    faces->clear();
+    faces->reserve(3 * n_triangles);
+    auto tri = [&](uint64_t a, uint64_t b, uint64_t c) {
+        faces->push_back(static_cast<uint32_t>(a)); faces->push_back(static_cast<uint32_t>(b)); faces->push_back(static_cast<uint32_t>(c));
+    };
+    auto ring = [&](uint64_t b, uint64_t c) { return 1 + (b - 1) * cols + (c % cols); };
+    for (uint64_t c = 0; c < cols; c++) tri(0, ring(1, c + 1), ring(1, c));
+    for (uint64_t b = 1; b + 1 < bands; b++)
+        for (uint64_t c = 0; c < cols; c++) {
+            tri(ring(b, c), ring(b, c + 1), ring(b + 1, c + 1));
+            tri(ring(b + 1, c + 1), ring(b + 1, c), ring(b, c));
+        }
+    for (uint64_t c = 0; c < cols; c++) tri(south, ring(bands - 1, c), ring(bands - 1, c + 1));
+    if (faces->size() / 3 != base) { *err = "stand-in: internal face count mismatch"; return RTX_ERR_INVALID; }
+
+    // centroid splits, spread evenly over the base triangles
+    uint64_t next_vertex = south + 1;
+    for (uint64_t e = 0; e < extra; e++) {
+        const uint64_t f = (e * base) / extra;
+        uint32_t a = (*faces)[3 * f], b = (*faces)[3 * f + 1], c = (*faces)[3 * f + 2];
+        double m[3];
+        for (int k = 0; k < 3; k++) m[k] = (raw[3 * a + k] + raw[3 * b + k] + raw[3 * c + k]) / 3;
+        push(m[0] * 1.002, m[1] * 1.002, m[2] * 1.002);
+        const uint64_t v = next_vertex++;
+        (*faces)[3 * f + 2] = static_cast<uint32_t>(v);       // (a, b, v)
+        tri(b, c, v);
+        tri(c, a, v);
+    }
+
+    // fit the model's bounding box to half_w x height x half_d, standing on y = 0
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    const uint64_t nv_model = raw.size() / 3;
+    for (uint64_t v = 0; v < nv_model; v++)
+        for (int k = 0; k < 3; k++) {
+            if (raw[3 * v + k] < lo[k]) lo[k] = raw[3 * v + k];
+            if (raw[3 * v + k] > hi[k]) hi[k] = raw[3 * v + k];
+        }
+    verts->clear();
+    verts->reserve(3 * (nv_model + 8));
+    for (uint64_t v = 0; v < nv_model; v++) {
+        double x = cx + (2 * (raw[3 * v] - lo[0]) / (hi[0] - lo[0]) - 1) * half_w;
+        double y = (raw[3 * v + 1] - lo[1]) / (hi[1] - lo[1]) * height;
+        double z = (2 * (raw[3 * v + 2] - lo[2]) / (hi[2] - lo[2]) - 1) * half_d;
+        verts->push_back(through_text(x)); verts->push_back(through_text(y)); verts->push_back(through_text(z));
+    }
+    // the box: floor y = 0, ceiling y = side, back wall z = +side/2, side walls; the
+    // front (towards the camera) stays open -- vertex order as teapot.obj's last 8
+    const double h = side / 2;
+    const double bx[8][3] = {{cx - h, 0, -h}, {cx + h, 0, -h}, {cx + h, 0, h}, {cx - h, 0, h},
+                             {cx - h, side, -h}, {cx + h, side, -h}, {cx + h, side, h}, {cx - h, side, h}};
+    for (const auto &p : bx) for (int k = 0; k < 3; k++) verts->push_back(through_text(p[k]));
+    // tools/range.py:40-51 (1-based there)
+    static const int box_faces[10][3] = {{1, 2, 3}, {3, 4, 1}, {5, 6, 7}, {7, 8, 5}, {4, 3, 7},
+                                         {7, 8, 4}, {3, 2, 6}, {6, 7, 3}, {1, 4, 8}, {8, 5, 1}};
+    for (const auto &f : box_faces) tri(nv_model + f[0] - 1, nv_model + f[1] - 1, nv_model + f[2] - 1);
+    if (faces->size() / 3 != n_triangles) { *err = "stand-in: internal total mismatch"; return RTX_ERR_INVALID; }
+    return RTX_OK;
+}
+
+// The reference's OBJ dialect: "v x y z" and "f i j k" (1-based), nothing else,
+// and NO trailing newline (see parse_obj for why that matters).
+int write_obj(const std::string &path, const std::vector<double> &verts, const std::vector<uint32_t> &faces,
+              std::string *err) {
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) { *err = "Failed to open file.\n"; return RTX_ERR_IO; }
+    std::vector<char> buf(1 << 20);
+    setvbuf(f, buf.data(), _IOFBF, buf.size());
+    for (size_t v = 0; v + 2 < verts.size(); v += 3) fprintf(f, "v %.9f %.9f %.9f\n", verts[v], verts[v + 1], verts[v + 2]);
+    const size_t nf = faces.size() / 3;
+    for (size_t t = 0; t < nf; t++)
+        fprintf(f, t + 1 < nf ? "f %u %u %u\n" : "f %u %u %u", faces[3 * t] + 1, faces[3 * t + 1] + 1, faces[3 * t + 2] + 1);
+    int bad = ferror(f);
+    bad |= fclose(f);
+    if (bad) { *err = "write failed: " + path; return RTX_ERR_IO; }
+    return RTX_OK;
+}
+
+}  // namespace rtx
