@@ -59,7 +59,7 @@ struct Out {
 };
 
 // One column strip, as the reference's render(scene, xMin, xMax) does it.
-void strip(Scene scene, int xMin, int xMax, int depth, Out *out) {
+void strip(Scene scene, int xMin, int xMax, int depth, Out *out, bool with_ids) {
     const int W = out->W, H = out->H;
     for (int x = xMin; x < xMax; x++) {
         // y spans [-H/2, H/2) for even H (src/main.cpp:77); an odd H gets its bottom row too.
@@ -68,13 +68,15 @@ void strip(Scene scene, int xMin, int xMax, int depth, Out *out) {
                               .rotateX(scene.cameraRotation.x)
                               .rotateY(scene.cameraRotation.y)
                               .rotateZ(scene.cameraRotation.z);
+            // the id/t dump costs one extra primary query per pixel; timing runs skip it
+            tuple<bool, double, int> prim = {false, 0.0, -2};
+            if (with_ids) {
 #if USE_BVH
-            tuple<bool, double, int> prim =
-                scene.bvh.intersectRay(scene.cameraPosition, ray, 1.0, INFINITY, 0);
+                prim = scene.bvh.intersectRay(scene.cameraPosition, ray, 1.0, INFINITY, 0);
 #else
-            tuple<bool, double, int> prim =
-                scene.closestIntersection(scene.cameraPosition, ray, 1.0, INFINITY);
+                prim = scene.closestIntersection(scene.cameraPosition, ray, 1.0, INFINITY);
 #endif
+            }
             Color c = scene.traceRay(scene.cameraPosition, ray, 1.0, INFINITY, depth);
             size_t i = static_cast<size_t>(-y + H / 2 - 1);
             size_t j = static_cast<size_t>(x + W / 2);
@@ -94,7 +96,7 @@ int main(int argc, char **argv) {
     if (argc < 7) {
         fprintf(stderr,
                 "usage: %s <teapot|bunny|erato|dragon|aurelius> <dir holding scenes/NAME.obj> "
-                "<W> <H> <depth> <out_prefix|-> [threads]\n",
+                "<W> <H> <depth> <out_prefix|-> [threads] [timing-only repeats]\n",
                 argv[0]);
         return 2;
     }
@@ -106,6 +108,8 @@ int main(int argc, char **argv) {
     int depth = atoi(argv[5]);
     std::string prefix = argv[6];
     int threads = argc > 7 ? atoi(argv[7]) : 8;
+    // > 0: render that many frames exactly as main() times them (no id query), print the seconds, dump nothing
+    int timing_repeats = argc > 8 ? atoi(argv[8]) : 0;
 
     // out_prefix is resolved against the original cwd, the scene factories
     // against `root` (they hard-code "scenes/NAME.obj", include/scene.hpp:262).
@@ -135,6 +139,20 @@ int main(int argc, char **argv) {
     out.rgb.assign(npx * 3, 0);
     out.t.assign(npx, 0.0);
 
+    const bool with_ids = timing_repeats == 0;
+    for (int rep = 1; rep < timing_repeats; rep++) {
+        auto a = std::chrono::high_resolution_clock::now();
+        std::vector<std::thread> pool;
+        int start = -out.W / 2, step = out.W / threads;
+        for (int i = 0; i < threads; i++) {
+            int x0 = start + i * step;
+            int x1 = (i == threads - 1) ? (out.W - out.W / 2) : x0 + step;
+            pool.emplace_back(strip, scene, x0, x1, depth, &out, false);
+        }
+        for (auto &th : pool) th.join();
+        auto b = std::chrono::high_resolution_clock::now();
+        printf("frame_seconds %.3f threads %d\n", std::chrono::duration<double>(b - a).count(), threads);
+    }
     auto t0 = std::chrono::high_resolution_clock::now();
     if (out.W > 0 && out.H > 0) {
         std::vector<std::thread> pool;
@@ -145,7 +163,7 @@ int main(int argc, char **argv) {
         for (int i = 0; i < threads; i++) {
             int x0 = start + i * step;
             int x1 = (i == threads - 1) ? (out.W - out.W / 2) : x0 + step;
-            pool.emplace_back(strip, scene, x0, x1, depth, &out);
+            pool.emplace_back(strip, scene, x0, x1, depth, &out, with_ids);
         }
         for (auto &th : pool) th.join();
     }
@@ -187,7 +205,7 @@ int main(int argc, char **argv) {
         printf("geometry_fnv %016llx\n", static_cast<unsigned long long>(h));
     }
 
-    if (prefix != "-") {
+    if (prefix != "-" && with_ids) {
         dump(prefix + ".hit.i32", out.hit.data(), npx * 4);
         dump(prefix + ".rgb.i32", out.rgb.data(), npx * 12);
         dump(prefix + ".rgb.u8", rgb8.data(), npx * 3);
