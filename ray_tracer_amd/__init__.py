@@ -108,6 +108,14 @@ def lib() -> C.CDLL:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RtxError(-3, f"{LIB_PATH} is missing: build it with `make -C ray_tracer_amd/csrc`")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so.  If it is loaded
+    # AFTER librtx.so has pulled in /opt/rocm's copy, the process holds two runtimes and the
+    # second one finds no GPU.  Importing torch first makes librtx.so bind to torch's copy
+    # (same soname), so device pointers and streams can be shared with torch tensors.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.rtx_last_error.restype = C.c_char_p

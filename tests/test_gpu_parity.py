@@ -48,3 +48,135 @@ def test_teapot_depths(teapot, depth):
         got = dev.render(128, 128, depth=depth, traversal=mode)
         assert np.array_equal(got.hit, want["hit"])
         assert np.array_equal(got.rgb, want["rgb_u8"])
+
+
+# ---------------------------------------------------------------- synthetic scenes
+from scenes_util import soup, untile_reference  # noqa: E402
+
+
+def _pair(seed, **kw):
+    v, col, spec, refl, cam = soup(seed, **kw)
+    host = rt.HostScene.from_arrays(v, col, spec, refl, **cam)
+    ora = OracleScene.from_arrays(v, col, spec, refl, **cam)
+    return host, rt.Scene(host), ora
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("mode", [rt.TRAVERSAL_REFERENCE, rt.TRAVERSAL_PRUNED])
+def test_soup_point_lights_rotations_bit_exact(seed, mode):
+    host, dev, ora = _pair(seed)
+    assert host.arrays()["nodes"].tobytes() == ora.nodes().tobytes()
+    want = ora.render(160, 120, depth=3)
+    got = dev.render(160, 120, depth=3, traversal=mode)
+    assert np.array_equal(got.hit, want["hit"])
+    assert np.array_equal(got.rgb, want["rgb_u8"])
+    dev.close()
+
+
+def test_soup_census(seed=4):
+    _, dev, ora = _pair(seed)
+    want = ora.render(96, 96, depth=2)["census"].as_dict()
+    got = dev.render(96, 96, depth=2, want_stats=True).stats.as_dict()
+    got.pop("kernel_ms")
+    assert got == want
+    dev.close()
+
+
+def test_soup_general_specular_exponent_within_one_lsb():
+    # pow(x, s) with s != 1 goes through the device libm: parity unpinned beyond +-1 LSB
+    _, dev, ora = _pair(5, exotic_spec=True)
+    want = ora.render(128, 96, depth=3)
+    got = dev.render(128, 96, depth=3)
+    assert np.array_equal(got.hit, want["hit"])
+    diff = np.abs(got.rgb.astype(int) - want["rgb_u8"].astype(int))
+    assert diff.max() <= 1
+    dev.close()
+
+
+def test_standin_bunny_small(tmp_path):
+    obj = str(tmp_path / "bunny.obj")
+    host = rt.HostScene.standin("bunny", 20010, seed=7, obj_path_out=obj)
+    ora = OracleScene.load_obj(obj, "bunny")          # the oracle parses the written file
+    assert host.n_triangles == ora.n_triangles == 20010
+    assert host.arrays()["nodes"].tobytes() == ora.nodes().tobytes()
+    dev = rt.Scene(host)
+    want = ora.render(192, 108, depth=3)
+    for mode in (rt.TRAVERSAL_REFERENCE, rt.TRAVERSAL_PRUNED):
+        got = dev.render(192, 108, depth=3, traversal=mode)
+        assert np.array_equal(got.hit, want["hit"])
+        assert np.array_equal(got.rgb, want["rgb_u8"])
+    dev.close()
+
+
+def test_supersampling_matches_oracle(teapot):
+    _, dev, ora = teapot
+    want = ora.render(96, 64, depth=3, spp=4, seed=11)
+    got = dev.render(96, 64, depth=3, spp=4, seed=11, traversal=rt.TRAVERSAL_PRUNED)
+    assert np.array_equal(got.hit, want["hit"])
+    assert np.array_equal(got.rgb, want["rgb_u8"])
+    # sample 0 has zero jitter: spp = 1 is the reference pixel
+    one = dev.render(96, 64, depth=3, spp=1)
+    assert np.array_equal(one.hit, got.hit)
+
+
+def test_window_and_odd_sizes(teapot):
+    _, dev, ora = teapot
+    W, H = 101, 67
+    want = ora.render(W, H, depth=3)
+    got = dev.render(W, H, depth=3)
+    assert np.array_equal(got.hit, want["hit"]) and np.array_equal(got.rgb, want["rgb_u8"])
+    win = dev.render(W, H, depth=3, window=(10, 50, 5, 40))
+    assert np.array_equal(win.rgb[5:40, 10:50], want["rgb_u8"][5:40, 10:50])
+    assert (win.hit[:5] == -1).all() and (win.rgb[:, 50:] == 0).all()
+    empty = dev.render(0, 0)
+    assert empty.rgb.size == 0
+
+
+def test_tiles_packed_and_untile_equals_full_frame(teapot):
+    import torch
+
+    _, dev, _ = teapot
+    W, H, tile, G = 200, 120, 16, 3
+    full = dev.render(W, H, depth=3, traversal=rt.TRAVERSAL_PRUNED)
+    parts = []
+    for r in range(G):
+        f = dev.render(W, H, depth=3, traversal=rt.TRAVERSAL_PRUNED, tile=(tile, tile), tile_rank=r, tile_count=G,
+                       layout=rt.LAYOUT_PACKED_TILES)
+        parts.append(f.rgb)
+    gathered = np.stack(parts)
+    assert np.array_equal(untile_reference(gathered, W, H, tile, tile, G), full.rgb)
+    g = torch.from_numpy(gathered).cuda()
+    out = torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda")
+    p = rt.make_params(W, H, tile=(tile, tile), tile_rank=0, tile_count=G, layout=rt.LAYOUT_PACKED_TILES)
+    rt.untile(p, G, g.data_ptr(), out.data_ptr(), 3, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().reshape(H, W, 3), full.rgb)
+
+
+def test_device_pointer_api_t_and_unclamped_rgb(teapot):
+    import torch
+
+    _, dev, ora = teapot
+    W, H = 128, 128
+    want = ora.render(W, H, depth=3, want_t=True)
+    rgb = torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda")
+    hit = torch.zeros(H * W, dtype=torch.int32, device="cuda")
+    rgb32 = torch.zeros(H * W * 3, dtype=torch.int32, device="cuda")
+    t = torch.zeros(H * W, dtype=torch.float64, device="cuda")
+    p = rt.make_params(W, H, depth=3, traversal=rt.TRAVERSAL_PRUNED)
+    dev.render_device(p, rgb_u8=rgb.data_ptr(), hit=hit.data_ptr(), rgb_i32=rgb32.data_ptr(), t=t.data_ptr(),
+                      stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(hit.cpu().numpy().reshape(H, W), want["hit"])
+    assert np.array_equal(rgb32.cpu().numpy().reshape(H, W, 3), want["rgb_i32"])
+    assert t.cpu().numpy().tobytes() == want["t"].tobytes()     # bit pattern, inf included
+
+
+def test_errors_do_not_cross_as_exceptions_from_c(teapot):
+    host, dev, _ = teapot
+    with pytest.raises(rt.RtxError):
+        dev.render(64, 64, depth=9)
+    with pytest.raises(rt.RtxError):
+        dev.render(64, 64, tile=(12, 8))
+    with pytest.raises(rt.RtxError):
+        rt.HostScene.load_obj("/nonexistent/file.obj", "teapot")
