@@ -188,6 +188,12 @@ int rtx_untile(const rtx_render_params *p, int32_t n_ranks, const void *d_gather
 /* saveCanvas (src/main.cpp:96-116): binary P6, "P6\n<W> <H> 255\n" + rows. */
 int rtx_save_ppm(const char *path, int32_t width, int32_t height, const uint8_t *rgb);
 
+/* Device self-test of the slab test's division-by-ray-constant: n seeded operand pairs
+ * (zeros, powers of two, all-ones significands, exponents over the admitted range) are
+ * divided both ways and compared bitwise; *mismatches must come back 0.
+ * No counterpart in the reference (it divides directly, include/bvh.hpp:218-229). */
+int rtx_selftest_division(uint64_t n, uint64_t seed, uint64_t *mismatches);
+
 const char *rtx_last_error(void);
 const char *rtx_version(void);
 

@@ -95,7 +95,7 @@ EXPORTS = (
     "rtx_host_scene_bvh_depth", "rtx_host_scene_set_camera", "rtx_host_scene_set_lights", "rtx_host_scene_free",
     "rtx_scene_create", "rtx_scene_create_from_host", "rtx_scene_destroy", "rtx_scene_device_bytes",
     "rtx_render_params_default", "rtx_output_pixels", "rtx_render", "rtx_render_device", "rtx_untile",
-    "rtx_save_ppm", "rtx_last_error", "rtx_version",
+    "rtx_save_ppm", "rtx_selftest_division", "rtx_last_error", "rtx_version",
 )
 
 _lib = None
@@ -144,6 +144,7 @@ def lib() -> C.CDLL:
     L.rtx_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, vp, vp, vp]
     L.rtx_untile.argtypes = [C.POINTER(RenderParams), C.c_int32, vp, vp, C.c_int32, vp]
     L.rtx_save_ppm.argtypes = [C.c_char_p, C.c_int32, C.c_int32, vp]
+    L.rtx_selftest_division.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
@@ -338,6 +339,13 @@ class Scene:
 
 def untile(params: RenderParams, n_ranks: int, gathered_ptr: int, out_ptr: int, bytes_per_pixel: int = 3, stream: int = 0):
     _check(lib().rtx_untile(C.byref(params), n_ranks, gathered_ptr, out_ptr, bytes_per_pixel, stream or None))
+
+
+def selftest_division(n: int, seed: int = 0) -> int:
+    """Mismatches between the slab test's fast division and the plain one over n seeded pairs (must be 0)."""
+    bad = C.c_uint64(0)
+    _check(lib().rtx_selftest_division(n, seed, C.byref(bad)))
+    return int(bad.value)
 
 
 def save_ppm(path: str, rgb: np.ndarray) -> None:

@@ -67,6 +67,9 @@ struct DevScene {
     double scene_scale;       // largest |coordinate| of the root box
     int32_t bg[3];
     int32_t bvh_depth;
+    // 1 when every box coordinate, the camera and the light positions are 0 or within
+    // 2^-300..2^300 and every box has min <= max: the slab test may divide through RayDiv
+    int32_t fast_div_ok;
 };
 
 struct DevRender {

@@ -335,6 +335,15 @@ int rtx_scene_create_from_host(const rtx_host_scene *hs, int32_t device, rtx_sce
         if (b > scale) scale = b;
     }
     d.scene_scale = scale;
+    // see RayDiv in rtx_kernels.hip: the slab test may replace its divisions only while
+    // every coordinate it subtracts is 0 or well inside the exponent range, and boxes are
+    // not inverted
+    auto tame = [](double v) { return v == 0.0 || (std::fabs(v) >= 0x1p-300 && std::fabs(v) <= 0x1p300); };
+    bool fast_ok = true;
+    for (const rtx_bvh_node &h : s.nodes)
+        for (int k = 0; k < 3; k++) fast_ok = fast_ok && tame(h.bmin[k]) && tame(h.bmax[k]) && h.bmin[k] <= h.bmax[k];
+    for (int k = 0; k < 3; k++) fast_ok = fast_ok && tame(s.camera_position[k]);
+    d.fast_div_ok = fast_ok ? 1 : 0;
     // Vector3::rotateX/Y/Z call cos(radians) and sin(radians) with
     // radians = (degrees / 180.0) * M_PI (util.hpp:12-14); same libm, same bits
     const double rx = (s.camera_rotation_deg[0] / 180.0) * M_PI, ry = (s.camera_rotation_deg[1] / 180.0) * M_PI,
@@ -480,6 +489,19 @@ int rtx_untile(const rtx_render_params *p, int32_t n_ranks, const void *d_gather
     const uint64_t rank_stride = packed_tiles_per_rank(rp.r) * (uint64_t)rp.r.tile_w * (uint64_t)rp.r.tile_h * (uint64_t)bpp;
     HIP_TRY(rtx::launch_untile((const uint8_t *)d_gathered, (uint8_t *)d_out, rp.r.W, rp.r.H, rp.r.tile_w, rp.r.tile_h,
                                rp.r.tiles_x, n_ranks, rank_stride, bpp, (hipStream_t)stream));
+    return RTX_OK;
+}
+
+int rtx_selftest_division(uint64_t n, uint64_t seed, uint64_t *mismatches) {
+    if (!mismatches) return fail(RTX_ERR_INVALID, "NULL argument");
+    unsigned long long *d = nullptr, h = 0;
+    HIP_TRY(hipMalloc((void **)&d, sizeof h));
+    hipError_t e = hipMemset(d, 0, sizeof h);
+    if (e == hipSuccess) e = rtx::launch_divtest(seed, n, d, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(RTX_ERR_DEVICE, std::string("division self-test: ") + hipGetErrorString(e));
+    *mismatches = h;
     return RTX_OK;
 }
 

@@ -20,6 +20,7 @@ inline size_t render_lds_bytes(int32_t bvh_depth, int32_t ray_depth, uint32_t bl
 
 hipError_t launch_render(const DevScene &sc, const DevRender &rp, bool prune, bool stats, uint32_t block_threads,
                          hipStream_t st);
+hipError_t launch_divtest(uint64_t seed, uint64_t n, unsigned long long *d_mismatches, hipStream_t st);
 hipError_t launch_untile(const uint8_t *src, uint8_t *dst, int W, int H, int tile_w, int tile_h, int tiles_x, int n_ranks,
                          uint64_t rank_stride, int bpp, hipStream_t st);
 

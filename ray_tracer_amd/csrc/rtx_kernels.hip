@@ -45,6 +45,58 @@ __device__ __forceinline__ double smax(double a, double b) { return (a < b) ? b 
 
 __device__ __forceinline__ V3 ld3(const double *p) { return {p[0], p[1], p[2]}; }
 
+// ---- exact division by a per-ray constant --------------------------------------
+// The slab test divides twelve box distances per node pair by the same three ray
+// components (bvh.hpp:218-229).  hipcc expands an IEEE f64 division into
+//   y0 = rcp(b); e = fma(-b,y0,1); y1 = fma(y0,e,y0); e = fma(-b,y1,1); y = fma(y1,e,y1);
+//   q0 = a*y; r = fma(-b,q0,a); q = fma(r,y,q0)
+// wrapped in v_div_scale / v_div_fmas / v_div_fixup, which only act on operands near
+// the ends of the exponent range, on zeros, infinities and NaNs.  The first line
+// depends on the divisor alone: RayDiv keeps y per ray component and the slab test
+// runs the second line only -- the same operations on the same values, hence the same
+// correctly rounded quotient -- provided every operand stays far from the exponent
+// range's ends (`ok`, checked per ray and per scene) or the divisor is zero (then
+// a / (+-0) = a * (+-inf) exactly, NaN for a = 0 included).
+struct RayDiv {
+    double nbx, nby, nbz;   // -r
+    double yx, yy, yz;      // refined reciprocals (+-inf for a zero component)
+    bool zx, zy, zz;        // component == 0
+    bool ok;                // fast path valid for this ray
+};
+
+__device__ __forceinline__ bool exp_safe(double v) {
+    // 0, or 2^-300 <= |v| <= 2^300
+    const uint32_t e = ((uint32_t)__double2hiint(v) >> 20) & 0x7ffu;
+    return v == 0.0 || (e >= 1023u - 300u && e <= 1023u + 300u);
+}
+
+__device__ __forceinline__ double refined_rcp(double b) {
+    double y0 = __builtin_amdgcn_rcp(b);
+    double e0 = __builtin_fma(-b, y0, 1.0);
+    double y1 = __builtin_fma(y0, e0, y0);
+    double e1 = __builtin_fma(-b, y1, 1.0);
+    return __builtin_fma(y1, e1, y1);
+}
+
+__device__ __forceinline__ RayDiv make_raydiv(V3 o, V3 r, bool scene_ok) {
+    RayDiv d;
+    d.nbx = -r.x; d.nby = -r.y; d.nbz = -r.z;
+    d.zx = r.x == 0.0; d.zy = r.y == 0.0; d.zz = r.z == 0.0;
+    d.yx = d.zx ? __builtin_copysign(RTX_INF, r.x) : refined_rcp(r.x);
+    d.yy = d.zy ? __builtin_copysign(RTX_INF, r.y) : refined_rcp(r.y);
+    d.yz = d.zz ? __builtin_copysign(RTX_INF, r.z) : refined_rcp(r.z);
+    d.ok = scene_ok && exp_safe(o.x) && exp_safe(o.y) && exp_safe(o.z) && exp_safe(r.x) && exp_safe(r.y) && exp_safe(r.z);
+    return d;
+}
+
+// a / b given nb = -b, y = refined_rcp(b), zero = (b == 0)
+__device__ __forceinline__ double div_by(double a, double nb, double y, bool zero) {
+    double q0 = a * y;
+    double rem = __builtin_fma(nb, q0, a);
+    double q1 = __builtin_fma(rem, y, q0);
+    return zero ? q0 : q1;
+}
+
 // BVH::intersectRayAABB with tLim = +inf (bvh.hpp:213-234; both call sites pass a
 // local closestT that is still INFINITY, bvh.hpp:170,174).  *tnear is the entry
 // distance the test computed.
@@ -55,6 +107,20 @@ __device__ __forceinline__ bool slab(const double *lo, const double *hi, V3 o, V
     tmin = smax(tmin, smin(ty1, ty2));
     tmax = smin(tmax, smax(ty1, ty2));
     double tz1 = (lo[2] - o.z) / r.z, tz2 = (hi[2] - o.z) / r.z;
+    tmin = smax(tmin, smin(tz1, tz2));
+    tmax = smin(tmax, smax(tz1, tz2));
+    *tnear = tmin;
+    return tmin < RTX_INF && tmax > 0 && tmax >= tmin;
+}
+
+// The same test with the divisions taken through RayDiv.
+__device__ __forceinline__ bool slab_fast(const double *lo, const double *hi, V3 o, const RayDiv &d, double *tnear) {
+    double tx1 = div_by(lo[0] - o.x, d.nbx, d.yx, d.zx), tx2 = div_by(hi[0] - o.x, d.nbx, d.yx, d.zx);
+    double tmin = smin(tx1, tx2), tmax = smax(tx1, tx2);
+    double ty1 = div_by(lo[1] - o.y, d.nby, d.yy, d.zy), ty2 = div_by(hi[1] - o.y, d.nby, d.yy, d.zy);
+    tmin = smax(tmin, smin(ty1, ty2));
+    tmax = smin(tmax, smax(ty1, ty2));
+    double tz1 = div_by(lo[2] - o.z, d.nbz, d.yz, d.zz), tz2 = div_by(hi[2] - o.z, d.nbz, d.yz, d.zz);
     tmin = smax(tmin, smin(tz1, tz2));
     tmax = smin(tmax, smax(tz1, tz2));
     *tnear = tmin;
@@ -95,15 +161,15 @@ struct Hit {
 // Result definition (bvh.hpp:178-208): smallest t among triangles with hit && tmin < t
 // < tmax; on equal t the triangle of the LATER leaf (larger leaf `first`) wins, inside
 // one leaf the earlier position wins.
-template <bool PRUNE, bool STATS>
-__device__ __forceinline__ Hit traverse(const DevScene &sc, V3 o, V3 r, double tmin, double tmax, bool any, double margin,
-                                        uint32_t *stack, uint32_t stride, Counters &c) {
+template <bool PRUNE, bool STATS, bool FAST>
+__device__ __forceinline__ Hit traverse(const DevScene &sc, V3 o, V3 r, const RayDiv &rd, double tmin, double tmax, bool any,
+                                        double margin, uint32_t *stack, uint32_t stride, Counters &c) {
     Hit best{RTX_INF, -1};
     uint32_t best_leaf = 0;
     const DevNode *nodes = sc.nodes;
     double tn;
     if (STATS) c.v[C_NODES]++;
-    if (!slab(nodes[1].bmin, nodes[1].bmax, o, r, &tn)) return best;
+    if (!(FAST ? slab_fast(nodes[1].bmin, nodes[1].bmax, o, rd, &tn) : slab(nodes[1].bmin, nodes[1].bmax, o, r, &tn))) return best;
     if (STATS) c.v[C_BOXHITS]++;
     uint32_t first = nodes[1].first, count = nodes[1].count;
     uint32_t sp = 0;
@@ -113,8 +179,8 @@ __device__ __forceinline__ Hit traverse(const DevScene &sc, V3 o, V3 r, double t
             const DevNode &L = nodes[first];
             const DevNode &R = nodes[first + 1];
             double tl, trr;
-            bool hl = slab(L.bmin, L.bmax, o, r, &tl);
-            bool hr = slab(R.bmin, R.bmax, o, r, &trr);
+            bool hl = FAST ? slab_fast(L.bmin, L.bmax, o, rd, &tl) : slab(L.bmin, L.bmax, o, r, &tl);
+            bool hr = FAST ? slab_fast(R.bmin, R.bmax, o, rd, &trr) : slab(R.bmin, R.bmax, o, r, &trr);
             if (STATS) { c.v[C_NODES] += 2; c.v[C_BOXHITS] += (hl ? 1 : 0) + (hr ? 1 : 0); }
             if (PRUNE) {
                 hl = hl && !(tl > limit + margin);
@@ -255,7 +321,10 @@ __global__ void __launch_bounds__(256) render_kernel(const DevScene sc, const De
         int cr = sc.bg[0], cg = sc.bg[1], cb = sc.bg[2];
         for (;;) {
             const double margin = PRUNE ? prune_margin(o, r, sc.scene_scale) : 0.0;
-            Hit h = traverse<PRUNE, STATS>(sc, o, r, tmin, tmax, kind == 1, margin, stack, stride, c);
+            const RayDiv rd = make_raydiv(o, r, sc.fast_div_ok != 0);
+            // the plain-division walk only runs for rays with components at the ends of the exponent range
+            Hit h = rd.ok ? traverse<PRUNE, STATS, true>(sc, o, r, rd, tmin, tmax, kind == 1, margin, stack, stride, c)
+                          : traverse<PRUNE, STATS, false>(sc, o, r, rd, tmin, tmax, kind == 1, margin, stack, stride, c);
             if (kind == 0) {
                 if (STATS) c.v[d == 0 ? C_PRIMARY : C_REFLECTION]++;
                 if (d == 0 && s == 0) {
@@ -354,6 +423,31 @@ __global__ void __launch_bounds__(256) render_kernel(const DevScene sc, const De
     }
 }
 
+// Self-test: div_by against the compiler's division on seeded operands, bitwise.
+__global__ void __launch_bounds__(256) divtest_kernel(uint64_t seed, uint64_t n, unsigned long long *mismatches) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t z = splitmix64(seed ^ (i * 0x9E3779B97F4A7C15ull));
+    uint64_t w = splitmix64(z);
+    // mantissas random, exponents in the range the fast path admits, both signs; every 64th divisor is +-0
+    // and every 97th dividend is 0
+    uint64_t ea = 1023 - 300 + (splitmix64(w) % 601), eb = 1023 - 300 + (splitmix64(w ^ 0x55) % 601);
+    if ((i & 7) < 6) { ea = 1023 - 12 + (splitmix64(w) % 24); eb = 1023 - 12 + (splitmix64(w ^ 0x55) % 24); }
+    uint64_t abits = (z & 0x800FFFFFFFFFFFFFull) | (ea << 52), bbits = (w & 0x800FFFFFFFFFFFFFull) | (eb << 52);
+    if ((i & 31) == 5) bbits |= 0x000FFFFFFFFFFFFFull;          // all-ones significand
+    if ((i & 31) == 6) bbits &= 0xFFF0000000000000ull;          // power of two
+    double a = __longlong_as_double((long long)abits), b = __longlong_as_double((long long)bbits);
+    if (i % 64 == 63) b = (i & 64) ? 0.0 : -0.0;
+    if (i % 97 == 96) a = (i & 128) ? 0.0 : -0.0;
+    V3 r = {b, 1.0, 1.0}, o = {0, 0, 0};
+    RayDiv d = make_raydiv(o, r, true);
+    double q = div_by(a, d.nbx, d.yx, d.zx);
+    double ref = a / b;
+    unsigned long long qb = (unsigned long long)__double_as_longlong(q), rb = (unsigned long long)__double_as_longlong(ref);
+    bool same = qb == rb || (q != q && ref != ref) || (q == 0.0 && ref == 0.0);   // NaN payload / sign of zero are free
+    if (!d.ok || !same) atomicAdd(mismatches, 1ull);
+}
+
 // [rank][local tile][tile_h][tile_w][bpp] -> row-major frame
 __global__ void __launch_bounds__(256) untile_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int W, int H,
                                                      int tile_w, int tile_h, int tiles_x, int n_ranks, uint64_t rank_stride,
@@ -385,6 +479,12 @@ hipError_t launch_render(const DevScene &sc, const DevRender &rp, bool prune, bo
     else if (prune) hipLaunchKernelGGL((render_kernel<true, false>), grid, block, lds, st, sc, rp);
     else if (stats) hipLaunchKernelGGL((render_kernel<false, true>), grid, block, lds, st, sc, rp);
     else hipLaunchKernelGGL((render_kernel<false, false>), grid, block, lds, st, sc, rp);
+    return hipGetLastError();
+}
+
+hipError_t launch_divtest(uint64_t seed, uint64_t n, unsigned long long *d_mismatches, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(divtest_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, seed, n, d_mismatches);
     return hipGetLastError();
 }
 

@@ -180,3 +180,9 @@ def test_errors_do_not_cross_as_exceptions_from_c(teapot):
         dev.render(64, 64, tile=(12, 8))
     with pytest.raises(rt.RtxError):
         rt.HostScene.load_obj("/nonexistent/file.obj", "teapot")
+
+
+def test_fast_division_is_bit_exact():
+    # 2^28 operand pairs per seed, compared bitwise with the compiler's IEEE division on the device
+    for seed in (1, 2):
+        assert rt.selftest_division(1 << 28, seed) == 0
