@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Generates the committed parity fixtures from the REFERENCE ITSELF.
+
+Runs only in the build container: it needs oracle/_ref/ref_bvh and ref_brute (the
+reference's own headers compiled from /root/reference, see oracle/ref_harness.cpp) and
+/root/reference/scenes/teapot.obj.  Outputs (all data, no reference source):
+
+  tests/golden/teapot.obj            the reference's scene file (input data)
+  tests/golden/golden.json           hashes / counts printed by the reference harness
+  tests/golden/teapot_128.npz        raw primary hit ids, unclamped RGB, primary t (128x128)
+  tests/golden/bunny20010_192x108.npz  same for a stand-in mesh (the reference parses the
+                                       .obj this repository's generator wrote)
+"""
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF_BVH = os.path.join(ROOT, "oracle", "_ref", "ref_bvh")
+REF_BRUTE = os.path.join(ROOT, "oracle", "_ref", "ref_brute")
+REFERENCE = "/root/reference"
+
+
+def run_ref(binary, scene, scene_root, W, H, depth, prefix="-", threads=8):
+    out = subprocess.run([binary, scene, scene_root, str(W), str(H), str(depth), prefix, str(threads)],
+                         check=True, capture_output=True, text=True).stdout
+    d = {}
+    for line in out.splitlines():
+        if line.startswith("["):
+            continue
+        k, *v = line.split()
+        d[k] = v[0] if len(v) == 1 else " ".join(v)
+    d.pop("frame_seconds", None)
+    return d
+
+
+def raw(prefix, W, H):
+    return dict(
+        hit=np.fromfile(prefix + ".hit.i32", dtype=np.int32).reshape(H, W),
+        rgb_i32=np.fromfile(prefix + ".rgb.i32", dtype=np.int32).reshape(H, W, 3),
+        t=np.fromfile(prefix + ".t.f64", dtype=np.float64).reshape(H, W),
+    )
+
+
+def main():
+    import ray_tracer_amd as rt
+
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    shutil.copyfile(os.path.join(REFERENCE, "scenes", "teapot.obj"), os.path.join(HERE, "teapot.obj"))
+    g = {"_generator": "tests/golden/make_golden.py", "_source": "oracle/_ref (reference headers compiled with g++ -O3)"}
+    with tempfile.TemporaryDirectory() as tmp:
+        # ---- teapot, the one scene the reference ships
+        g["teapot_200_bvh"] = run_ref(REF_BVH, "teapot", REFERENCE, 200, 200, 3)
+        g["teapot_200_brute"] = run_ref(REF_BRUTE, "teapot", REFERENCE, 200, 200, 3)
+        p = os.path.join(tmp, "t128")
+        g["teapot_128"] = run_ref(REF_BVH, "teapot", REFERENCE, 128, 128, 3, p)
+        np.savez_compressed(os.path.join(HERE, "teapot_128.npz"), **raw(p, 128, 128))
+        p = os.path.join(tmp, "t1920")
+        g["teapot_1920"] = run_ref(REF_BVH, "teapot", REFERENCE, 1920, 1920, 3, p)
+        ppm = b"P6\n1920 1920 255\n" + open(p + ".rgb.u8", "rb").read()
+        g["teapot_1920"]["ppm_md5"] = hashlib.md5(ppm).hexdigest()
+        g["teapot_1920x1080"] = run_ref(REF_BVH, "teapot", REFERENCE, 1920, 1080, 3)
+        for depth in (0, 1):
+            g[f"teapot_160x96_depth{depth}"] = run_ref(REF_BVH, "teapot", REFERENCE, 160, 96, depth)
+        # the loader quirk: a trailing newline duplicates the last face
+        os.makedirs(os.path.join(tmp, "nl", "scenes"))
+        with open(os.path.join(tmp, "nl", "scenes", "teapot.obj"), "wb") as f:
+            f.write(open(os.path.join(REFERENCE, "scenes", "teapot.obj"), "rb").read() + b"\n")
+        g["teapot_trailing_newline_64"] = run_ref(REF_BVH, "teapot", os.path.join(tmp, "nl"), 64, 64, 3)
+        # ---- stand-in meshes: this repository's generator writes the .obj, the reference renders it
+        cases = [("bunny", 20010, 7, 192, 108, True), ("bunny", 144056, 0, 480, 270, False),
+                 ("erato", 412508, 0, 480, 270, False), ("dragon", 871316, 0, 960, 540, False),
+                 ("aurelius", 1704768, 0, 480, 270, False)]
+        for scene, ntri, seed, W, H, keep_raw in cases:
+            root = os.path.join(tmp, f"{scene}{ntri}")
+            os.makedirs(os.path.join(root, "scenes"))
+            obj = os.path.join(root, "scenes", f"{scene}.obj")
+            rt.HostScene.standin(scene, ntri, seed=seed, obj_path_out=obj).close()
+            key = f"standin_{scene}_{ntri}_seed{seed}_{W}x{H}"
+            p = os.path.join(tmp, key)
+            g[key] = run_ref(REF_BVH, scene, root, W, H, 3, p if keep_raw else "-")
+            g[key]["obj_md5"] = hashlib.md5(open(obj, "rb").read()).hexdigest()
+            if keep_raw:
+                np.savez_compressed(os.path.join(HERE, f"{scene}{ntri}_{W}x{H}.npz"), **raw(p, W, H))
+            shutil.rmtree(root)
+            print(key, g[key]["hit_fnv"], flush=True)
+    with open(os.path.join(HERE, "golden.json"), "w") as f:
+        json.dump(g, f, indent=1, sort_keys=True)
+    print("wrote", os.path.join(HERE, "golden.json"))
+
+
+if __name__ == "__main__":
+    main()

@@ -48,3 +48,18 @@ def owned_tiles(W, H, tile_w, tile_h, rank, n_ranks):
     tiles_x = (W + tile_w - 1) // tile_w
     tiles_y = (H + tile_h - 1) // tile_h
     return [k for k in range(tiles_x * tiles_y) if k % n_ranks == rank]
+
+
+def pack_reference(frame, tile_w, tile_h, rank, n_ranks):
+    """numpy restatement of the packed layout one rank renders: [local tile][tile_h][tile_w][bpp]."""
+    H, W, bpp = frame.shape
+    tiles_x = (W + tile_w - 1) // tile_w
+    tiles_y = (H + tile_h - 1) // tile_h
+    per_rank = (tiles_x * tiles_y + n_ranks - 1) // n_ranks
+    out = np.zeros((per_rank, tile_h, tile_w, bpp), dtype=frame.dtype)
+    for k in owned_tiles(W, H, tile_w, tile_h, rank, n_ranks):
+        ty, tx = divmod(k, tiles_x)
+        y0, x0 = ty * tile_h, tx * tile_w
+        h, w = min(tile_h, H - y0), min(tile_w, W - x0)
+        out[k // n_ranks, :h, :w] = frame[y0:y0 + h, x0:x0 + w]
+    return out

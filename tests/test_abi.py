@@ -1,0 +1,43 @@
+"""The C ABI: librtx.so loads without a GPU and exports every function include/rtx.h declares."""
+import ctypes
+import os
+import re
+
+import ray_tracer_amd as rt
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "rtx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rtx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported():
+    lib = ctypes.CDLL(rt.LIB_PATH)
+    names = declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"librtx.so does not export {n}"
+    assert sorted(rt.EXPORTS) == names
+
+
+def test_struct_sizes_match_the_header():
+    assert ctypes.sizeof(rt.BvhNode) == 64          # the reference's BVHNode
+    assert ctypes.sizeof(rt.Light) == 32
+    assert ctypes.sizeof(rt.RenderParams) == 64
+    assert ctypes.sizeof(rt.Stats) == 80
+
+
+def test_host_only_calls_work_without_gpu():
+    lib = rt.lib()
+    assert lib.rtx_version().startswith(b"rtx-mi355x")
+    p = rt.make_params(100, 60, tile=(16, 8), tile_rank=1, tile_count=4, layout=rt.LAYOUT_PACKED_TILES)
+    # 7 x 8 = 56 tiles over 4 ranks -> 14 each
+    assert lib.rtx_output_pixels(ctypes.byref(p)) == 14 * 16 * 8
+    p = rt.make_params(100, 60)
+    assert lib.rtx_output_pixels(ctypes.byref(p)) == 6000
+    p.depth = 99
+    assert lib.rtx_output_pixels(ctypes.byref(p)) == 0
+    assert b"depth" in lib.rtx_last_error()

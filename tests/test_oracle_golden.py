@@ -1,0 +1,98 @@
+"""Pins the oracle: the CPU restatement must reproduce what the reference itself printed
+(tests/golden/golden.json and the .npz arrays come from oracle/_ref, i.e. the reference's own
+headers compiled in the build container -- see tests/golden/make_golden.py)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle_binding import OracleScene, fnv1a
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "golden.json")))
+
+
+@pytest.fixture(scope="module")
+def teapot(teapot_obj):
+    return OracleScene.load_obj(teapot_obj, "teapot")
+
+
+def _check_render(r, want, with_t=True):
+    assert fnv1a(r["hit"]) == want["hit_fnv"]
+    assert fnv1a(r["rgb_i32"]) == want["rgb_i32_fnv"]
+    assert fnv1a(r["rgb_u8"]) == want["rgb_u8_fnv"]
+    if with_t:
+        assert fnv1a(r["t"]) == want["t_fnv"]
+
+
+def test_bvh_arrays_equal_reference(teapot, golden):
+    want = golden["teapot_128"]
+    assert teapot.n_triangles == int(want["triangles"]) == 6330
+    assert teapot.n_nodes == int(want["nodes_used"]) == 12541
+    assert fnv1a(teapot.nodes()) == want["nodes_fnv"]
+    assert fnv1a(teapot.indices()) == want["indices_fnv"]
+    assert fnv1a(teapot.geometry()) == want["geometry_fnv"]
+
+
+def test_teapot_128_raw_arrays(teapot, golden_dir):
+    want = np.load(os.path.join(golden_dir, "teapot_128.npz"))
+    got = teapot.render(128, 128, depth=3, want_t=True)
+    assert np.array_equal(got["hit"], want["hit"])
+    assert np.array_equal(got["rgb_i32"], want["rgb_i32"])
+    assert got["t"].tobytes() == want["t"].tobytes()
+
+
+def test_teapot_bvh_equals_brute_force_200(teapot, golden):
+    assert golden["teapot_200_bvh"]["hit_fnv"] == golden["teapot_200_brute"]["hit_fnv"] == "8eb9504b74001932"
+    assert golden["teapot_200_bvh"]["rgb_i32_fnv"] == golden["teapot_200_brute"]["rgb_i32_fnv"]
+    _check_render(teapot.render(200, 200, depth=3, want_t=True), golden["teapot_200_bvh"])
+    small = teapot.render(48, 48, depth=3, use_bvh=False)
+    ref = teapot.render(48, 48, depth=3, use_bvh=True)
+    assert np.array_equal(small["hit"], ref["hit"]) and np.array_equal(small["rgb_i32"], ref["rgb_i32"])
+
+
+def test_teapot_full_size_hashes_md5_and_census(teapot, golden):
+    want = golden["teapot_1920"]
+    r = teapot.render(1920, 1920, depth=3, want_t=True)
+    _check_render(r, want)
+    ppm = b"P6\n1920 1920 255\n" + r["rgb_u8"].tobytes()
+    assert hashlib.md5(ppm).hexdigest() == want["ppm_md5"] == "7f1565d293e2de8d48dabc57bbfd2907"
+    c = r["census"].as_dict()
+    # ray census of the stock 1920x1920 teapot frame measured on the reference
+    assert c["primary_rays"] == 3686400 and c["reflection_rays"] == 9056499
+    assert c["shadow_rays"] == 9831612 and c["shadow_occluded"] == 3981949
+    assert c["rays"] == 22574511
+
+
+def test_teapot_non_square_and_depths(teapot, golden):
+    _check_render(teapot.render(1920, 1080, depth=3, want_t=True), golden["teapot_1920x1080"])
+    for depth in (0, 1):
+        _check_render(teapot.render(160, 96, depth=depth, want_t=True), golden[f"teapot_160x96_depth{depth}"])
+
+
+def test_loader_duplicates_last_face_after_trailing_newline(teapot_obj, golden, tmp_path):
+    p = tmp_path / "teapot_nl.obj"
+    p.write_bytes(open(teapot_obj, "rb").read() + b"\n")
+    s = OracleScene.load_obj(str(p), "teapot")
+    want = golden["teapot_trailing_newline_64"]
+    assert s.n_triangles == int(want["triangles"]) == 6331
+    _check_render(s.render(64, 64, depth=3, want_t=True), want)
+
+
+def test_standin_raw_arrays_from_reference(golden, golden_dir, tmp_path):
+    import ray_tracer_amd as rt
+
+    obj = str(tmp_path / "bunny.obj")
+    rt.HostScene.standin("bunny", 20010, seed=7, obj_path_out=obj).close()
+    want = golden["standin_bunny_20010_seed7_192x108"]
+    assert hashlib.md5(open(obj, "rb").read()).hexdigest() == want["obj_md5"]
+    s = OracleScene.load_obj(obj, "bunny")
+    assert fnv1a(s.nodes()) == want["nodes_fnv"] and fnv1a(s.indices()) == want["indices_fnv"]
+    arr = np.load(os.path.join(golden_dir, "bunny20010_192x108.npz"))
+    got = s.render(192, 108, depth=3, want_t=True)
+    assert np.array_equal(got["hit"], arr["hit"]) and np.array_equal(got["rgb_i32"], arr["rgb_i32"])
+    assert got["t"].tobytes() == arr["t"].tobytes()
