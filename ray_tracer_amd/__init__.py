@@ -14,7 +14,8 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtx.so")
+# RTX_LIB selects another build of the library (A/B runs of kernel variants)
+LIB_PATH = os.environ.get("RTX_LIB") or os.path.join(_HERE, "librtx.so")
 
 TRAVERSAL_REFERENCE = 0
 TRAVERSAL_PRUNED = 1

@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -263,6 +264,10 @@ int rtx_scene_create_from_host(const rtx_host_scene *hs, int32_t device, rtx_sce
     // triangle array because that array IS BVH::indices order
     std::vector<rtx::DevNode> nodes(m + 1);
     memset(nodes.data(), 0, nodes.size() * sizeof(rtx::DevNode));
+    // slot 0 pairs with the root (slot 1); NaN bounds fail every slab test, so a walk that
+    // starts as the pair test of (0, 1) tests exactly the root
+    for (int k = 0; k < 3; k++) { nodes[0].bmin[k] = std::nan(""); nodes[0].bmax[k] = std::nan(""); }
+    nodes[0].count = 0; nodes[0].first = 0;
     for (uint64_t i = 0; i < m; i++) {
         const rtx_bvh_node &h = s.nodes[i];
         rtx::DevNode &d = nodes[i + 1];
@@ -421,10 +426,38 @@ int rtx_render_device(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8,
     if (rtx::render_lds_bytes(sc->dev.bvh_depth, r.depth, block) > 65536)
         return fail(RTX_ERR_UNSUPPORTED, "BVH deeper than 255 levels: traversal stack does not fit LDS");
     r.stack_stride = block;
+    // Tuning knobs of the wave scheduler (environment overrides are for experiments).
+    auto knob = [](const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; };
+    int chunk = knob("RTX_CHUNK", 64);
+    if (chunk < 64) chunk = 64;
+    r.chunk = (uint32_t)(chunk / 64 * 64);
+    r.w_inner = knob("RTX_W_INNER", 1);
+    r.w_leaf = knob("RTX_W_LEAF", 2);
+    r.w_shade = knob("RTX_W_SHADE", 2);
+    if (r.w_inner < 1 || r.w_leaf < 1 || r.w_shade < 1) return fail(RTX_ERR_INVALID, "scheduler weights must be positive");
     if (r.W == 0 || r.H == 0 || r.owned_tiles == 0) return RTX_OK;
     DeviceGuard guard(sc->device);
     if (!guard.ok) return fail(RTX_ERR_DEVICE, "cannot select the scene's device");
+    // Diagnostics: RTX_WAVE_LOG=<file> records every wave's start/end tick (100 MHz) of this
+    // launch and writes them as raw u64 pairs.  Synchronous; never set in production.
+    const char *log_path = getenv("RTX_WAVE_LOG");
+    unsigned long long *d_log = nullptr;
+    uint64_t n_waves = 0;
+    if (log_path && *log_path) {
+        const uint64_t tile_pixels = (uint64_t)r.tile_w * r.tile_h;
+        n_waves = ((tile_pixels + r.chunk - 1) / r.chunk) * (uint64_t)r.owned_tiles;
+        n_waves = (n_waves + 3) / 4 * 4;
+        HIP_TRY(hipMalloc((void **)&d_log, n_waves * 16));
+        HIP_TRY(hipMemset(d_log, 0, n_waves * 16));
+        r.wave_log = d_log;
+    }
     HIP_TRY(rtx::launch_render(sc->dev, r, p->traversal == RTX_TRAVERSAL_PRUNED, d_stats != nullptr, block, (hipStream_t)stream));
+    if (d_log) {
+        std::vector<unsigned long long> h(n_waves * 2);
+        HIP_TRY(hipMemcpy(h.data(), d_log, n_waves * 16, hipMemcpyDeviceToHost));
+        (void)hipFree(d_log);
+        if (FILE *f = fopen(log_path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+    }
     return RTX_OK;
 }
 

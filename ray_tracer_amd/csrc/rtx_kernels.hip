@@ -22,6 +22,11 @@ namespace rtx {
 namespace {
 
 #define RTX_INF (__builtin_inf())
+// second __launch_bounds__ argument of the render kernel: waves per SIMD the register
+// allocator must leave room for
+#ifndef RTX_WAVES_PER_EU
+#define RTX_WAVES_PER_EU 2
+#endif
 // include/common.hpp:12: DBL_EPSILON * 2^20 = 2^-32
 #define RTX_EPS (2.3283064365386962890625e-10)
 
@@ -100,30 +105,40 @@ __device__ __forceinline__ double div_by(double a, double nb, double y, bool zer
 // BVH::intersectRayAABB with tLim = +inf (bvh.hpp:213-234; both call sites pass a
 // local closestT that is still INFINITY, bvh.hpp:170,174).  *tnear is the entry
 // distance the test computed.
-__device__ __forceinline__ bool slab(const double *lo, const double *hi, V3 o, V3 r, double *tnear) {
+// *beyond: some axis' entry distance exceeds that axis' limit `lim` (PRUNE only).
+__device__ __forceinline__ bool slab(const double *lo, const double *hi, V3 o, V3 r, V3 lim, double *tnear, bool *beyond) {
     double tx1 = (lo[0] - o.x) / r.x, tx2 = (hi[0] - o.x) / r.x;
-    double tmin = smin(tx1, tx2), tmax = smax(tx1, tx2);
+    double nx = smin(tx1, tx2);
+    double tmin = nx, tmax = smax(tx1, tx2);
     double ty1 = (lo[1] - o.y) / r.y, ty2 = (hi[1] - o.y) / r.y;
-    tmin = smax(tmin, smin(ty1, ty2));
+    double ny = smin(ty1, ty2);
+    tmin = smax(tmin, ny);
     tmax = smin(tmax, smax(ty1, ty2));
     double tz1 = (lo[2] - o.z) / r.z, tz2 = (hi[2] - o.z) / r.z;
-    tmin = smax(tmin, smin(tz1, tz2));
+    double nz = smin(tz1, tz2);
+    tmin = smax(tmin, nz);
     tmax = smin(tmax, smax(tz1, tz2));
     *tnear = tmin;
+    *beyond = nx > lim.x || ny > lim.y || nz > lim.z;
     return tmin < RTX_INF && tmax > 0 && tmax >= tmin;
 }
 
 // The same test with the divisions taken through RayDiv.
-__device__ __forceinline__ bool slab_fast(const double *lo, const double *hi, V3 o, const RayDiv &d, double *tnear) {
+__device__ __forceinline__ bool slab_fast(const double *lo, const double *hi, V3 o, const RayDiv &d, V3 lim, double *tnear,
+                                          bool *beyond) {
     double tx1 = div_by(lo[0] - o.x, d.nbx, d.yx, d.zx), tx2 = div_by(hi[0] - o.x, d.nbx, d.yx, d.zx);
-    double tmin = smin(tx1, tx2), tmax = smax(tx1, tx2);
+    double nx = smin(tx1, tx2);
+    double tmin = nx, tmax = smax(tx1, tx2);
     double ty1 = div_by(lo[1] - o.y, d.nby, d.yy, d.zy), ty2 = div_by(hi[1] - o.y, d.nby, d.yy, d.zy);
-    tmin = smax(tmin, smin(ty1, ty2));
+    double ny = smin(ty1, ty2);
+    tmin = smax(tmin, ny);
     tmax = smin(tmax, smax(ty1, ty2));
     double tz1 = div_by(lo[2] - o.z, d.nbz, d.yz, d.zz), tz2 = div_by(hi[2] - o.z, d.nbz, d.yz, d.zz);
-    tmin = smax(tmin, smin(tz1, tz2));
+    double nz = smin(tz1, tz2);
+    tmin = smax(tmin, nz);
     tmax = smin(tmax, smax(tz1, tz2));
     *tnear = tmin;
+    *beyond = nx > lim.x || ny > lim.y || nz > lim.z;
     return tmin < RTX_INF && tmax > 0 && tmax >= tmin;
 }
 
@@ -146,107 +161,29 @@ struct Counters {
 };
 enum { C_PRIMARY, C_REFLECTION, C_SHADOW, C_OCCLUDED, C_CLOSEST, C_NODES, C_BOXHITS, C_LEAVES, C_TRIS };
 
-struct Hit {
-    double t;
-    int32_t pos;      // position in the device triangle array, -1 = miss
-};
-
-// Closest hit over the BVH.
-//   PRUNE = false: visits exactly the node set of the reference's recursion (a child is
-//           entered iff its slab test passes) and keeps scanning after a hit.
-//   PRUNE = true : near child first, skips a child whose entry distance is beyond the
-//           best hit so far (+ margin, see prune_margin) and, when `any` is set (a
-//           shadow query only asks whether a hit exists, scene.hpp:155-163), stops
-//           at the first accepted triangle.  Results are the same.
-// Result definition (bvh.hpp:178-208): smallest t among triangles with hit && tmin < t
-// < tmax; on equal t the triangle of the LATER leaf (larger leaf `first`) wins, inside
-// one leaf the earlier position wins.
-template <bool PRUNE, bool STATS, bool FAST>
-__device__ __forceinline__ Hit traverse(const DevScene &sc, V3 o, V3 r, const RayDiv &rd, double tmin, double tmax, bool any,
-                                        double margin, uint32_t *stack, uint32_t stride, Counters &c) {
-    Hit best{RTX_INF, -1};
-    uint32_t best_leaf = 0;
-    const DevNode *nodes = sc.nodes;
-    double tn;
-    if (STATS) c.v[C_NODES]++;
-    if (!(FAST ? slab_fast(nodes[1].bmin, nodes[1].bmax, o, rd, &tn) : slab(nodes[1].bmin, nodes[1].bmax, o, r, &tn))) return best;
-    if (STATS) c.v[C_BOXHITS]++;
-    uint32_t first = nodes[1].first, count = nodes[1].count;
-    uint32_t sp = 0;
-    double limit = tmax;   // PRUNE: no accepted t can be >= tmax
-    for (;;) {
-        if (count == 0) {
-            const DevNode &L = nodes[first];
-            const DevNode &R = nodes[first + 1];
-            double tl, trr;
-            bool hl = FAST ? slab_fast(L.bmin, L.bmax, o, rd, &tl) : slab(L.bmin, L.bmax, o, r, &tl);
-            bool hr = FAST ? slab_fast(R.bmin, R.bmax, o, rd, &trr) : slab(R.bmin, R.bmax, o, r, &trr);
-            if (STATS) { c.v[C_NODES] += 2; c.v[C_BOXHITS] += (hl ? 1 : 0) + (hr ? 1 : 0); }
-            if (PRUNE) {
-                hl = hl && !(tl > limit + margin);
-                hr = hr && !(trr > limit + margin);
-            }
-            uint32_t lf = L.first, lc = L.count, rf = R.first, rc = R.count;
-            if (hl && hr) {
-                bool right_first = PRUNE && (trr < tl);
-                stack[sp * stride] = right_first ? first : first + 1;
-                sp++;
-                first = right_first ? rf : lf;
-                count = right_first ? rc : lc;
-                continue;
-            } else if (hl) {
-                first = lf; count = lc;
-                continue;
-            } else if (hr) {
-                first = rf; count = rc;
-                continue;
-            }
-        } else {
-            if (STATS) { c.v[C_LEAVES]++; c.v[C_TRIS] += count; }
-            for (uint32_t i = 0; i < count; i++) {
-                const DevTri &tr = sc.tris[first + i];
-                double t;
-                if (tri_hit(tr, o, r, &t) && t > tmin && t < tmax) {
-                    if (PRUNE && any) return Hit{t, (int32_t)(first + i)};
-                    uint32_t lfirst = first;   // == tr.leaf_first
-                    bool better = t < best.t || (t == best.t && (lfirst > best_leaf));
-                    // same leaf, equal t: the earlier position stays (strict <, bvh.hpp:186)
-                    if (better) {
-                        best.t = t; best.pos = (int32_t)(first + i); best_leaf = lfirst;
-                        if (PRUNE) limit = t;
-                    }
-                }
-            }
-        }
-        if (sp == 0) break;
-        sp--;
-        uint32_t slot = stack[sp * stride];
-        first = nodes[slot].first;
-        count = nodes[slot].count;
-    }
-    return best;
-}
-
 __device__ __forceinline__ V3 reflect_ray(V3 ray, V3 n) {              // scene.hpp:185-187
     return sub(muls(smul(2.0, n), dot(n, ray)), ray);
 }
 
-// Distance slack for PRUNE.  A triangle's t comes from the plane equation
-// (triangle.hpp:40) and a box's entry distance from three divisions (bvh.hpp:218-231);
-// both describe the same geometric fact with different roundings.  The accepted hit
-// point lies within rounding distance of its triangle, hence of every box that holds
-// it; along the ray that is a t-difference of at most (point slack) / |r_axis| on the
-// axis that bounds the entry.  The slack below is a 2^-20 relative bound on the
-// point, 2^32 times the rounding unit, the same factor the reference's own EPSILON
-// uses.
-__device__ __forceinline__ double prune_margin(V3 o, V3 r, double scene_scale) {
-    double ax = __builtin_fabs(r.x), ay = __builtin_fabs(r.y), az = __builtin_fabs(r.z);
-    double m = RTX_INF;
-    if (ax > 0 && ax < m) m = ax;
-    if (ay > 0 && ay < m) m = ay;
-    if (az > 0 && az < m) m = az;
-    double reach = scene_scale + __builtin_fabs(o.x) + __builtin_fabs(o.y) + __builtin_fabs(o.z);
-    return (reach * 9.5367431640625e-07) / m;
+// Distance pruning (PRUNE) skips a box when, on SOME axis, the ray enters the box's slab
+// later than limit + slack, where limit is the best accepted t so far (or tmax).
+// Why a slack: a triangle's t comes from the plane equation (triangle.hpp:40), a slab
+// entry from a division (bvh.hpp:218-229) -- the same geometry, rounded differently.  The
+// accepted hit point o + t*r passed the inside tests and lies within rounding distance
+// (a few ulps of the scene's extent) of its triangle, hence of every box that holds the
+// triangle; on axis i that bounds t from below by entry_i - (point slack) / |r_i|.
+// `slack_point` is 2^-20 of the reach (scene extent + |origin|), 2^32 rounding units --
+// the factor the reference's own EPSILON uses -- and 1/|r_i| is taken from the ray's
+// refined reciprocal (times 2 for its rounding).  An axis the ray barely moves along gets
+// a huge slack and simply never prunes; the other axes still do.
+__device__ __forceinline__ double slack_point(V3 o, double scene_scale) {
+    const double reach = scene_scale + __builtin_fabs(o.x) + __builtin_fabs(o.y) + __builtin_fabs(o.z);
+    return reach * 1.9073486328125e-06;   // 2^-19
+}
+__device__ __forceinline__ V3 prune_limits(double limit, double slack, const RayDiv &d) {
+    // limit + slack * |1/r_i|; a zero component has y = inf -> never prunes on that axis
+    return {__builtin_fma(slack, __builtin_fabs(d.yx), limit), __builtin_fma(slack, __builtin_fabs(d.yy), limit),
+            __builtin_fma(slack, __builtin_fabs(d.yz), limit)};
 }
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
@@ -258,168 +195,389 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
 
 __device__ __forceinline__ int clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }   // color.hpp:23-29
 
-// One lane = one pixel.  The lane runs a small state machine around ONE traversal
-// loop: a closest-hit query (kind 0) is followed by one shadow query per light
-// (kind 1, scene.hpp:155), then either the path ends or the reflected ray
-// (scene.hpp:119-120) becomes the next closest-hit query.  The (localColor,
-// reflectivity) pairs waiting for their reflected colour (scene.hpp:122) sit in LDS
-// behind the traversal stack.
+// ---------------------------------------------------------------------------------
+// The render kernel.
+//
+// A wave owns a chunk of up to `chunk` pixels of one screen tile (8x8-pixel blocks in
+// row-major order, so the 64 lanes start on one block).  A lane carries one pixel at a
+// time through the reference's per-pixel work and then draws the next pixel of the
+// chunk, so lanes whose pixel was cheap (background) do not idle while neighbours
+// follow three reflections.
+//
+// The per-pixel work is cut into three kinds of step, and in every round the wave
+// runs ONE kind, the one most lanes are waiting for (ballot + popcount), instead of
+// running all kinds with the lanes that need them masked in turn:
+//   INNER  one BVH inner node: both children (one 128-byte line) slab-tested, far child
+//          pushed on the lane's LDS stack                      (bvh.hpp:197-208,213-234)
+//   LEAF   one triangle of a leaf                               (bvh.hpp:178-195, triangle.hpp:32-55)
+//   SHADE  a finished query: a closest-hit result starts the shadow query of the first
+//          light, a shadow result adds that light's term and starts the next light's
+//          query, the last one finishes the surface colour and either reflects or ends
+//          the pixel (scene.hpp:89-183); lanes without a pixel fetch one here.
+// BVH::intersectRay's recursion becomes this walk; its result is kept exactly:
+// smallest t with hit && tmin < t < tmax; equal t -> the triangle of the later leaf
+// (larger leaf `first`), inside one leaf the earlier triangle (bvh.hpp:186,204-208).
+//   PRUNE = false: a child is entered iff its slab test passes, shadow queries walk
+//           everything: exactly the reference's node visits.
+//   PRUNE = true : near child first; a child whose entry distance lies beyond the best
+//           hit so far (+ prune_margin) is skipped; a shadow query stops at its first
+//           accepted triangle.  Same results, less work.
+enum : int { ST_INNER = 0, ST_LEAF = 1, ST_SHADE = 2, ST_FETCH = 3, ST_DONE = 4 };
+
+struct Lane {
+    // current query
+    V3 o, r;
+    RayDiv rd;
+    double tmin, tmax, slack;
+    V3 lim;              // PRUNE: per-axis entry limits (prune_limits)
+    double best_t;
+    int32_t best_pos;
+    uint32_t best_leaf;
+    uint32_t first, count, sp;
+    int state;
+    // the surface hit being shaded and the pixel's path
+    int kind;            // 0 closest-hit query, 1 shadow query of light `li`
+    int d;               // reflections so far = entries waiting in the LDS blend stack
+    uint32_t li;
+    V3 v;                // -ray at the surface hit
+    int32_t pos;         // its triangle
+    double total;        // computeTotalLighting accumulator
+    // the pixel
+    int col, row, s;
+    uint32_t in_x, in_y;
+    int sum_r, sum_g, sum_b, first_r, first_g, first_b;
+};
+
+__device__ __forceinline__ void start_query(Lane &L, const DevScene &sc, bool prune) {
+    L.rd = make_raydiv(L.o, L.r, sc.fast_div_ok != 0);
+    L.slack = prune ? slack_point(L.o, sc.scene_scale) : 0.0;
+    // no accepted t can reach tmax, so tmax is the first limit
+    L.lim = prune ? prune_limits(L.tmax, L.slack, L.rd) : V3{RTX_INF, RTX_INF, RTX_INF};
+    L.best_t = RTX_INF;
+    L.best_pos = -1;
+    L.best_leaf = 0;
+    // slot 0 holds a box no ray enters and slot 1 the root: the walk starts as the pair
+    // test of (0, 1), which is the root's own slab test (bvh.hpp:174)
+    L.first = 0;
+    L.count = 0;
+    L.sp = 0;
+    L.state = ST_INNER;
+}
+
+__device__ __forceinline__ void pop_node(Lane &L, const DevNode *nodes, const uint32_t *stack, uint32_t stride) {
+    if (L.sp == 0) {
+        L.state = ST_SHADE;
+        return;
+    }
+    L.sp--;
+    const uint32_t slot = stack[L.sp * stride];
+    L.first = nodes[slot].first;
+    L.count = nodes[slot].count;
+    L.state = L.count ? ST_LEAF : ST_INNER;
+}
+
 template <bool PRUNE, bool STATS>
-__global__ void __launch_bounds__(256) render_kernel(const DevScene sc, const DevRender rp) {
+__device__ __forceinline__ void inner_step(Lane &L, const DevScene &sc, uint32_t *stack, uint32_t stride, Counters &c) {
+    const DevNode *nodes = sc.nodes;
+    const DevNode &A = nodes[L.first];
+    const DevNode &B = nodes[L.first + 1];
+    double ta, tb;
+    bool ha, hb, beyond_a, beyond_b;
+    if (L.rd.ok) {
+        ha = slab_fast(A.bmin, A.bmax, L.o, L.rd, L.lim, &ta, &beyond_a);
+        hb = slab_fast(B.bmin, B.bmax, L.o, L.rd, L.lim, &tb, &beyond_b);
+    } else {   // ray components at the ends of the exponent range: plain divisions
+        ha = slab(A.bmin, A.bmax, L.o, L.r, L.lim, &ta, &beyond_a);
+        hb = slab(B.bmin, B.bmax, L.o, L.r, L.lim, &tb, &beyond_b);
+    }
+    if (STATS) {
+        c.v[C_NODES] += L.first ? 2 : 1;      // slot 0 is not a node of the tree
+        c.v[C_BOXHITS] += (ha ? 1 : 0) + (hb ? 1 : 0);
+    }
+    if (PRUNE) {
+        ha = ha && !beyond_a;
+        hb = hb && !beyond_b;
+    }
+    const uint32_t af = A.first, ac = A.count, bf = B.first, bc = B.count;
+    if (ha && hb) {
+        const bool b_first = PRUNE && (tb < ta);
+        stack[L.sp * stride] = b_first ? L.first : L.first + 1;
+        L.sp++;
+        L.first = b_first ? bf : af;
+        L.count = b_first ? bc : ac;
+        L.state = L.count ? ST_LEAF : ST_INNER;
+    } else if (ha) {
+        L.first = af; L.count = ac;
+        L.state = L.count ? ST_LEAF : ST_INNER;
+    } else if (hb) {
+        L.first = bf; L.count = bc;
+        L.state = L.count ? ST_LEAF : ST_INNER;
+    } else {
+        pop_node(L, nodes, stack, stride);
+    }
+}
+
+template <bool PRUNE, bool STATS>
+__device__ __forceinline__ void leaf_step(Lane &L, const DevScene &sc, const uint32_t *stack, uint32_t stride, Counters &c) {
+    const DevTri &tr = sc.tris[L.first];
+    if (STATS) {
+        c.v[C_TRIS]++;
+        if (L.first == tr.leaf_first) c.v[C_LEAVES]++;
+    }
+    double t;
+    if (tri_hit(tr, L.o, L.r, &t) && t > L.tmin && t < L.tmax) {
+        const uint32_t leaf = tr.leaf_first;
+        // equal t inside one leaf: the earlier triangle stays (strict <, bvh.hpp:186)
+        if (t < L.best_t || (t == L.best_t && leaf > L.best_leaf)) {
+            L.best_t = t;
+            L.best_pos = (int32_t)L.first;
+            L.best_leaf = leaf;
+            if (PRUNE) {
+                L.lim = prune_limits(t, L.slack, L.rd);
+                if (L.kind == 1) {         // a shadow query only asks whether a hit exists
+                    L.state = ST_SHADE;
+                    return;
+                }
+            }
+        }
+    }
+    L.first++;
+    L.count--;
+    if (L.count == 0) pop_node(L, sc.nodes, stack, stride);
+}
+
+// src/main.cpp:78-83: camera ray of pixel (col,row), sample s
+__device__ __forceinline__ void primary_ray(Lane &L, const DevScene &sc, const DevRender &rp) {
+    // putPixel inverted (src/main.cpp:90-94): row = -y + H/2 - 1, col = x + W/2
+    const int x = L.col - rp.W / 2, y = rp.H / 2 - 1 - L.row;
+    double fx = (double)x, fy = (double)y;
+    if (L.s > 0) {   // samples > 0 add a jitter in [0,1)^2 (this build's extension)
+        const uint64_t k = (uint64_t)L.row * (uint64_t)rp.W + (uint64_t)L.col;
+        uint64_t z = splitmix64(splitmix64(rp.seed) ^ k);
+        z = splitmix64(z ^ ((uint64_t)(uint32_t)L.s << 32));
+        fx = fx + (double)(z >> 32) * (1.0 / 4294967296.0);
+        fy = fy + (double)(z & 0xFFFFFFFFull) * (1.0 / 4294967296.0);
+    }
+    // Scene::toViewport (scene.hpp:81-87), then rotateX, rotateY, rotateZ (vector3.hpp:54-82)
+    V3 vp = {fx * rp.px, fy * rp.py, sc.viewport[2]};
+    V3 rx = {vp.x, sc.cx * vp.y - sc.sx * vp.z, sc.sx * vp.y + sc.cx * vp.z};
+    V3 ry = {sc.cy * rx.x + sc.sy * rx.z, rx.y, (-sc.sy) * rx.x + sc.cy * rx.z};
+    L.r = {sc.cz * ry.x - sc.sz * ry.y, sc.sz * ry.x + sc.cz * ry.y, ry.z};
+    L.o = {sc.cam[0], sc.cam[1], sc.cam[2]};
+    L.tmin = 1.0;
+    L.tmax = RTX_INF;
+    L.kind = 0;
+    L.d = 0;
+}
+
+// A finished query (scene.hpp:89-183).  Leaves the lane with a new query (ST_INNER) or
+// without a pixel (ST_FETCH).
+template <bool PRUNE, bool STATS>
+__device__ __forceinline__ void shade_step(Lane &L, const DevScene &sc, const DevRender &rp, uint32_t *pend, uint32_t stride,
+                                           uint32_t local_tile, Counters &c) {
+    const uint32_t n_lights = sc.n_point + sc.n_dir;
+    bool path_done = false;
+    int cr = sc.bg[0], cg = sc.bg[1], cb = sc.bg[2];
+    bool lights = false;
+    if (L.kind == 0) {
+        // Scene::traceRay after the closest-hit query (scene.hpp:97-111)
+        if (STATS) c.v[L.d == 0 ? C_PRIMARY : C_REFLECTION]++;
+        if (L.d == 0 && L.s == 0) {
+            const uint64_t k = (uint64_t)L.row * (uint64_t)rp.W + (uint64_t)L.col;
+            if (rp.hit) rp.hit[k] = (L.best_pos >= 0) ? (int32_t)sc.tris[L.best_pos].orig_id : -1;
+            if (rp.t) rp.t[k] = L.best_t;
+        }
+        if (L.best_pos < 0) {
+            path_done = true;                                           // backgroundColor, scene.hpp:101-103
+        } else {
+            if (STATS) c.v[C_CLOSEST]++;
+            L.o = add(L.o, smul(L.best_t, L.r));                        // point, scene.hpp:105
+            L.v = muls(L.r, -1.0);                                      // -ray, vector3.hpp:108-110
+            L.pos = L.best_pos;
+            L.total = sc.ambient;                                       // scene.hpp:128
+            L.li = 0;
+            lights = true;
+        }
+    } else {
+        // the rest of Scene::computeLighting (scene.hpp:159-182) with light = r, point = o
+        if (STATS) { c.v[C_SHADOW]++; if (L.best_pos >= 0) c.v[C_OCCLUDED]++; }
+        if (L.best_pos < 0) {
+            const V3 n = ld3(sc.tris[L.pos].n);
+            const int spec = sc.mats[L.pos].specularity;
+            const double intensity = sc.lights[L.li].intensity;
+            double term = 0.0;
+            const double nl = dot(n, L.r);
+            if (nl > 0.0) term += intensity * (nl / (mag(n) * mag(L.r)));
+            if (spec != -1) {
+                const V3 R = reflect_ray(L.r, n);
+                const double rv = dot(R, L.v);
+                if (rv > 0) {
+                    const double cosv = rv / (mag(R) * mag(L.v));
+                    // pow(x, 1) is x exactly in every libm; other exponents go through the
+                    // device pow, which may differ from glibc's in the last place
+                    term += intensity * ((spec == 1) ? cosv : pow(cosv, (double)spec));
+                }
+            }
+            L.total += term;
+        }
+        L.li++;
+        lights = true;
+    }
+    if (lights) {
+        if (L.li < n_lights) {
+            // computeTotalLighting (scene.hpp:130-142): point lights first (light = position -
+            // point, tMax = 1), then directional ones (light = direction, tMax = inf)
+            const bool is_point = L.li < sc.n_point;
+            const V3 lv = ld3(sc.lights[L.li].v);
+            L.r = is_point ? sub(lv, L.o) : lv;
+            L.tmin = 0.001;
+            L.tmax = is_point ? 1.0 : RTX_INF;
+            L.kind = 1;
+            start_query(L, sc, PRUNE);
+            return;
+        }
+        // Color * double truncates each channel (color.hpp:47-53)
+        const DevMat &mt = sc.mats[L.pos];
+        const int lr = (int)(mt.color[0] * L.total), lg = (int)(mt.color[1] * L.total), lb = (int)(mt.color[2] * L.total);
+        const double refl = mt.reflectivity;
+        if (L.d == rp.depth || refl < 0) {                              // scene.hpp:115-117
+            cr = lr; cg = lg; cb = lb;
+            path_done = true;
+        } else {
+            uint32_t *e = pend + (uint32_t)L.d * 5u * stride;
+            e[0] = (uint32_t)lr; e[stride] = (uint32_t)lg; e[2 * stride] = (uint32_t)lb;
+            e[3 * stride] = (uint32_t)__double2loint(refl); e[4 * stride] = (uint32_t)__double2hiint(refl);
+            L.d++;
+            L.r = reflect_ray(L.v, ld3(sc.tris[L.pos].n));              // scene.hpp:119
+            L.tmin = 0.001;
+            L.tmax = RTX_INF;
+            L.kind = 0;
+            start_query(L, sc, PRUNE);
+            return;
+        }
+    }
+    if (!path_done) return;
+    // localColor * (1 - reflectivity) + reflectedColor * reflectivity (scene.hpp:122), innermost first
+    while (L.d > 0) {
+        L.d--;
+        const uint32_t *e = pend + (uint32_t)L.d * 5u * stride;
+        const int lr = (int)e[0], lg = (int)e[stride], lb = (int)e[2 * stride];
+        const double refl = __hiloint2double((int)e[4 * stride], (int)e[3 * stride]);
+        const double keep = 1 - refl;
+        cr = (int)(lr * keep) + (int)(cr * refl);
+        cg = (int)(lg * keep) + (int)(cg * refl);
+        cb = (int)(lb * keep) + (int)(cb * refl);
+    }
+    if (L.s == 0) { L.first_r = cr; L.first_g = cg; L.first_b = cb; }
+    L.sum_r += clamp255(cr); L.sum_g += clamp255(cg); L.sum_b += clamp255(cb);
+    L.s++;
+    if (L.s < rp.spp) {
+        primary_ray(L, sc, rp);
+        start_query(L, sc, PRUNE);
+        return;
+    }
+    // putPixel (src/main.cpp:90-94) + the clamp of saveCanvas (src/main.cpp:107)
+    uint64_t out = (uint64_t)L.row * (uint64_t)rp.W + (uint64_t)L.col;
+    if (rp.layout == RTX_LAYOUT_PACKED_TILES_)
+        out = ((uint64_t)local_tile * (uint32_t)rp.tile_h + L.in_y) * (uint32_t)rp.tile_w + L.in_x;
+    if (rp.rgb) {
+        const int spp = rp.spp;
+        rp.rgb[3 * out + 0] = (uint8_t)((L.sum_r + spp / 2) / spp);
+        rp.rgb[3 * out + 1] = (uint8_t)((L.sum_g + spp / 2) / spp);
+        rp.rgb[3 * out + 2] = (uint8_t)((L.sum_b + spp / 2) / spp);
+    }
+    if (rp.rgb_i32) {
+        rp.rgb_i32[3 * out + 0] = rp.spp == 1 ? L.first_r : L.sum_r;
+        rp.rgb_i32[3 * out + 1] = rp.spp == 1 ? L.first_g : L.sum_g;
+        rp.rgb_i32[3 * out + 2] = rp.spp == 1 ? L.first_b : L.sum_b;
+    }
+    L.state = ST_FETCH;
+}
+
+template <bool PRUNE, bool STATS>
+__global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const DevScene sc, const DevRender rp) {
     extern __shared__ uint32_t lds[];
-    const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t waves_per_block = blockDim.x >> 6;
-    const uint32_t blocks_x = (uint32_t)rp.tile_w >> 3, blocks_y = (uint32_t)rp.tile_h >> 3;
-    const uint32_t per_tile = blocks_x * blocks_y;
+    const uint32_t blocks_x = (uint32_t)rp.tile_w >> 3;
+    const uint32_t tile_pixels = (uint32_t)rp.tile_w * (uint32_t)rp.tile_h;
+    const uint32_t chunks_per_tile = (tile_pixels + rp.chunk - 1) / rp.chunk;
     const uint64_t gw = (uint64_t)blockIdx.x * waves_per_block + wave;
-    const uint32_t local_tile = (uint32_t)(gw / per_tile);
-    const uint32_t wb = (uint32_t)(gw % per_tile);
+    const uint32_t local_tile = (uint32_t)(gw / chunks_per_tile);
     if (local_tile >= (uint32_t)rp.owned_tiles) return;
     const uint32_t tile = (rp.tile_count > 1) ? local_tile * (uint32_t)rp.tile_count + (uint32_t)rp.tile_rank : local_tile;
-    const uint32_t tx = tile % (uint32_t)rp.tiles_x, ty = tile / (uint32_t)rp.tiles_x;
-    const uint32_t in_x = (wb % blocks_x) * 8u + (lane & 7u), in_y = (wb / blocks_x) * 8u + (lane >> 3);
-    const int col = (int)(tx * (uint32_t)rp.tile_w + in_x), row = (int)(ty * (uint32_t)rp.tile_h + in_y);
-    if (col < rp.x0 || col >= rp.x1 || row < rp.y0 || row >= rp.y1) return;
+    const uint32_t tile_x0 = (tile % (uint32_t)rp.tiles_x) * (uint32_t)rp.tile_w;
+    const uint32_t tile_y0 = (tile / (uint32_t)rp.tiles_x) * (uint32_t)rp.tile_h;
+    // pixel slots [slot_next, slot_end) of the tile belong to this wave (wave-uniform)
+    uint32_t slot_next = (uint32_t)(gw % chunks_per_tile) * rp.chunk;
+    const uint32_t slot_end = min(slot_next + rp.chunk, tile_pixels);
 
+    const unsigned long long wave_t0 = rp.wave_log ? wall_clock64() : 0;
     const uint32_t stride = rp.stack_stride;
     uint32_t *stack = lds + threadIdx.x;
     uint32_t *pend = lds + (uint32_t)(sc.bvh_depth + 1) * stride + threadIdx.x;   // [level][5][lane]
     Counters c;
     if (STATS) for (int i = 0; i < 9; i++) c.v[i] = 0;
 
-    // putPixel inverted (src/main.cpp:90-94): row = -y + H/2 - 1, col = x + W/2
-    const int x = col - rp.W / 2, y = rp.H / 2 - 1 - row;
-    const uint64_t k = (uint64_t)row * (uint64_t)rp.W + (uint64_t)col;
-    const uint32_t n_lights = sc.n_point + sc.n_dir;
+    Lane L;
+    L.state = ST_FETCH;
+    L.kind = 0; L.d = 0; L.li = 0; L.pos = -1; L.total = 0.0; L.v = {0, 0, 0};
+    L.o = {0, 0, 0}; L.r = {0, 0, 1};
+    L.first = 0; L.count = 0; L.sp = 0;
+    L.best_t = RTX_INF; L.best_pos = -1; L.best_leaf = 0;
+    L.tmin = 0; L.tmax = 0; L.slack = 0; L.lim = {0, 0, 0};
+    L.col = 0; L.row = 0; L.s = 0; L.in_x = 0; L.in_y = 0;
+    L.sum_r = L.sum_g = L.sum_b = L.first_r = L.first_g = L.first_b = 0;
+    L.rd = make_raydiv(L.o, L.r, false);
 
-    int sum_r = 0, sum_g = 0, sum_b = 0;
-    int first_r = 0, first_g = 0, first_b = 0;
-    for (int s = 0; s < rp.spp; s++) {
-        // Scene::toViewport (scene.hpp:81-87); samples > 0 add a jitter in [0,1)^2
-        double fx = (double)x, fy = (double)y;
-        if (s > 0) {
-            uint64_t z = splitmix64(splitmix64(rp.seed) ^ k);
-            z = splitmix64(z ^ ((uint64_t)(uint32_t)s << 32));
-            fx = fx + (double)(z >> 32) * (1.0 / 4294967296.0);
-            fy = fy + (double)(z & 0xFFFFFFFFull) * (1.0 / 4294967296.0);
-        }
-        V3 vp = {fx * rp.px, fy * rp.py, sc.viewport[2]};
-        // rotateX, rotateY, rotateZ (vector3.hpp:54-82)
-        V3 rx = {vp.x, sc.cx * vp.y - sc.sx * vp.z, sc.sx * vp.y + sc.cx * vp.z};
-        V3 ry = {sc.cy * rx.x + sc.sy * rx.z, rx.y, (-sc.sy) * rx.x + sc.cy * rx.z};
-        V3 r = {sc.cz * ry.x - sc.sz * ry.y, sc.sz * ry.x + sc.cz * ry.y, ry.z};
-        V3 o = {sc.cam[0], sc.cam[1], sc.cam[2]};
-        double tmin = 1.0, tmax = RTX_INF;                              // src/main.cpp:83
-
-        int kind = 0;          // 0 closest-hit query, 1 shadow query for light `li`
-        int d = 0;             // reflections so far = entries in pend[]
-        uint32_t li = 0;
-        V3 v = {0, 0, 0};      // -ray of the surface hit being shaded
-        int32_t pos = -1;      // its triangle (device position)
-        double total = 0.0;    // computeTotalLighting accumulator
-        int cr = sc.bg[0], cg = sc.bg[1], cb = sc.bg[2];
-        for (;;) {
-            const double margin = PRUNE ? prune_margin(o, r, sc.scene_scale) : 0.0;
-            const RayDiv rd = make_raydiv(o, r, sc.fast_div_ok != 0);
-            // the plain-division walk only runs for rays with components at the ends of the exponent range
-            Hit h = rd.ok ? traverse<PRUNE, STATS, true>(sc, o, r, rd, tmin, tmax, kind == 1, margin, stack, stride, c)
-                          : traverse<PRUNE, STATS, false>(sc, o, r, rd, tmin, tmax, kind == 1, margin, stack, stride, c);
-            if (kind == 0) {
-                if (STATS) c.v[d == 0 ? C_PRIMARY : C_REFLECTION]++;
-                if (d == 0 && s == 0) {
-                    if (rp.hit) rp.hit[k] = (h.pos >= 0) ? (int32_t)sc.tris[h.pos].orig_id : -1;
-                    if (rp.t) rp.t[k] = h.t;
-                }
-                if (h.pos < 0) break;                                   // backgroundColor, scene.hpp:101-103
-                if (STATS) c.v[C_CLOSEST]++;
-                o = add(o, smul(h.t, r));                               // point, scene.hpp:105
-                v = muls(r, -1.0);                                      // -ray, vector3.hpp:108-110
-                pos = h.pos;
-                total = sc.ambient;                                     // scene.hpp:128
-                li = 0;
-            } else {
-                // the rest of Scene::computeLighting (scene.hpp:159-182) with light = r, point = o
-                if (STATS) { c.v[C_SHADOW]++; if (h.pos >= 0) c.v[C_OCCLUDED]++; }
-                if (h.pos < 0) {
-                    const V3 n = ld3(sc.tris[pos].n);
-                    const int spec = sc.mats[pos].specularity;
-                    const double intensity = sc.lights[li].intensity;
-                    double term = 0.0;
-                    double nl = dot(n, r);
-                    if (nl > 0.0) term += intensity * (nl / (mag(n) * mag(r)));
-                    if (spec != -1) {
-                        V3 R = reflect_ray(r, n);
-                        double rv = dot(R, v);
-                        if (rv > 0) {
-                            double cosv = rv / (mag(R) * mag(v));
-                            // pow(x, 1) is x exactly in every libm; other exponents go through
-                            // the device pow, which may differ from glibc's in the last place
-                            term += intensity * ((spec == 1) ? cosv : pow(cosv, (double)spec));
+    for (;;) {
+        const unsigned long long m_inner = __ballot(L.state == ST_INNER);
+        const unsigned long long m_leaf = __ballot(L.state == ST_LEAF);
+        const unsigned long long m_shade = __ballot(L.state == ST_SHADE || L.state == ST_FETCH);
+        if ((m_inner | m_leaf | m_shade) == 0) break;                   // every lane ST_DONE
+        // wave-uniform choice: the kind of step most lanes wait for (weighted)
+        const int w_inner = __popcll(m_inner) * rp.w_inner, w_leaf = __popcll(m_leaf) * rp.w_leaf,
+                  w_shade = __popcll(m_shade) * rp.w_shade;
+        if (w_inner >= w_leaf && w_inner >= w_shade) {
+            if (L.state == ST_INNER) inner_step<PRUNE, STATS>(L, sc, stack, stride, c);
+        } else if (w_leaf >= w_shade) {
+            if (L.state == ST_LEAF) leaf_step<PRUNE, STATS>(L, sc, stack, stride, c);
+        } else {
+            if (L.state == ST_SHADE) shade_step<PRUNE, STATS>(L, sc, rp, pend, stride, local_tile, c);
+            // lanes without a pixel draw the next slots of the chunk, in lane order
+            const unsigned long long need = __ballot(L.state == ST_FETCH);
+            if (need) {
+                if (L.state == ST_FETCH) {
+                    const uint32_t lane = threadIdx.x & 63u;
+                    const uint32_t slot = slot_next + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                    if (slot >= slot_end) {
+                        L.state = ST_DONE;
+                    } else {
+                        const uint32_t blk = slot >> 6, in = slot & 63u;
+                        L.in_x = (blk % blocks_x) * 8u + (in & 7u);
+                        L.in_y = (blk / blocks_x) * 8u + (in >> 3);
+                        L.col = (int)(tile_x0 + L.in_x);
+                        L.row = (int)(tile_y0 + L.in_y);
+                        // outside the frame or the window: nothing to render, fetch again next time
+                        if (L.col >= rp.x0 && L.col < rp.x1 && L.row >= rp.y0 && L.row < rp.y1) {
+                            L.s = 0;
+                            L.sum_r = L.sum_g = L.sum_b = 0;
+                            primary_ray(L, sc, rp);
+                            start_query(L, sc, PRUNE);
                         }
                     }
-                    total += term;
                 }
-                li++;
+                slot_next += (uint32_t)__popcll(need);
             }
-            if (li < n_lights) {
-                // computeTotalLighting (scene.hpp:130-142): point lights first (light = position -
-                // point, tMax = 1), then directional (light = direction, tMax = inf)
-                const bool is_point = li < sc.n_point;
-                V3 lv = ld3(sc.lights[li].v);
-                r = is_point ? sub(lv, o) : lv;
-                tmin = 0.001;
-                tmax = is_point ? 1.0 : RTX_INF;
-                kind = 1;
-                continue;
-            }
-            // Color * double truncates each channel (color.hpp:47-53)
-            const DevMat &mt = sc.mats[pos];
-            const int lr = (int)(mt.color[0] * total), lg = (int)(mt.color[1] * total), lb = (int)(mt.color[2] * total);
-            const double refl = mt.reflectivity;
-            cr = lr; cg = lg; cb = lb;
-            if (d == rp.depth || refl < 0) break;                       // scene.hpp:115-117
-            uint32_t *e = pend + (uint32_t)d * 5u * stride;
-            e[0] = (uint32_t)lr; e[stride] = (uint32_t)lg; e[2 * stride] = (uint32_t)lb;
-            e[3 * stride] = (uint32_t)__double2loint(refl); e[4 * stride] = (uint32_t)__double2hiint(refl);
-            d++;
-            r = reflect_ray(v, ld3(sc.tris[pos].n));                    // scene.hpp:119
-            tmin = 0.001; tmax = RTX_INF;
-            kind = 0;
-            cr = sc.bg[0]; cg = sc.bg[1]; cb = sc.bg[2];
         }
-        // localColor * (1 - reflectivity) + reflectedColor * reflectivity (scene.hpp:122), innermost first
-        while (d > 0) {
-            d--;
-            const uint32_t *e = pend + (uint32_t)d * 5u * stride;
-            const int lr = (int)e[0], lg = (int)e[stride], lb = (int)e[2 * stride];
-            const double refl = __hiloint2double((int)e[4 * stride], (int)e[3 * stride]);
-            const double keep = 1 - refl;
-            cr = (int)(lr * keep) + (int)(cr * refl);
-            cg = (int)(lg * keep) + (int)(cg * refl);
-            cb = (int)(lb * keep) + (int)(cb * refl);
-        }
-        if (s == 0) { first_r = cr; first_g = cg; first_b = cb; }
-        sum_r += clamp255(cr); sum_g += clamp255(cg); sum_b += clamp255(cb);
-    }
-
-    uint64_t out = k;
-    if (rp.layout == RTX_LAYOUT_PACKED_TILES_)
-        out = ((uint64_t)local_tile * (uint32_t)rp.tile_h + in_y) * (uint32_t)rp.tile_w + in_x;
-    if (rp.rgb) {
-        const int spp = rp.spp;
-        rp.rgb[3 * out + 0] = (uint8_t)((sum_r + spp / 2) / spp);
-        rp.rgb[3 * out + 1] = (uint8_t)((sum_g + spp / 2) / spp);
-        rp.rgb[3 * out + 2] = (uint8_t)((sum_b + spp / 2) / spp);
-    }
-    if (rp.rgb_i32) {
-        rp.rgb_i32[3 * out + 0] = rp.spp == 1 ? first_r : sum_r;
-        rp.rgb_i32[3 * out + 1] = rp.spp == 1 ? first_g : sum_g;
-        rp.rgb_i32[3 * out + 2] = rp.spp == 1 ? first_b : sum_b;
     }
     if (STATS && rp.stats) {
         for (int i = 0; i < 9; i++)
             if (c.v[i]) atomicAdd(&rp.stats[i], c.v[i]);
+    }
+    if (rp.wave_log && (threadIdx.x & 63u) == 0) {
+        rp.wave_log[2 * gw] = wave_t0;
+        rp.wave_log[2 * gw + 1] = wall_clock64();
     }
 }
 
@@ -466,14 +624,14 @@ __global__ void __launch_bounds__(256) untile_kernel(const uint8_t *__restrict__
 
 hipError_t launch_render(const DevScene &sc, const DevRender &rp, bool prune, bool stats, uint32_t block_threads,
                          hipStream_t st) {
-    const uint64_t per_tile = (uint64_t)(rp.tile_w / 8) * (uint64_t)(rp.tile_h / 8);
-    const uint64_t waves = per_tile * (uint64_t)rp.owned_tiles;
+    const uint64_t tile_pixels = (uint64_t)rp.tile_w * (uint64_t)rp.tile_h;
+    const uint64_t chunks_per_tile = (tile_pixels + rp.chunk - 1) / rp.chunk;
+    const uint64_t waves = chunks_per_tile * (uint64_t)rp.owned_tiles;
     if (waves == 0) return hipSuccess;
     const uint32_t wpb = block_threads / 64;
     const uint64_t blocks = (waves + wpb - 1) / wpb;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     dim3 grid((uint32_t)blocks), block(block_threads);
-    // one u32 per level per lane; a walk never holds more entries than the tree is deep
     const size_t lds = render_lds_bytes(sc.bvh_depth, rp.depth, block_threads);
     if (prune && stats) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, lds, st, sc, rp);
     else if (prune) hipLaunchKernelGGL((render_kernel<true, false>), grid, block, lds, st, sc, rp);

@@ -1,7 +1,8 @@
 // Stand-in meshes for the four scenes whose .obj files cannot ship with this
 // repository (bunny 144 056, erato 412 508, dragon 871 316, aurelius 1 704 768
 // faces; include/scene.hpp:294,333,372,411).  A stand-in is a closed, bumpy,
-// star-shaped surface tessellated to exactly n - 10 triangles, standing on the
+// star-shaped surface (a displaced cube-sphere: evenly shaped triangles like a
+// scanned mesh) tessellated to exactly n - 10 triangles, standing on the
 // floor of the 10-triangle open box the reference scenes end with
 // (tools/range.py:40-54 gives the box faces; :24-32 the ratio of the mesh's
 // bounding-box volume to the box volume, 27360/216000).
@@ -42,19 +43,20 @@ int generate_standin(const std::string &preset, uint64_t n_triangles, uint64_t s
     HostScene probe;
     probe.vertices.assign(90, 0.0);
     if (int rc = apply_preset(&probe, preset, err)) return rc;
-    if (n_triangles < 10 + 8) { *err = "stand-in needs at least 18 triangles"; return RTX_ERR_INVALID; }
+    if (n_triangles < 10 + 12) { *err = "stand-in needs at least 22 triangles"; return RTX_ERR_INVALID; }
     if ((n_triangles - 10) % 2) { *err = "stand-in triangle count must be even"; return RTX_ERR_INVALID; }
     const uint64_t target = n_triangles - 10;
 
-    // UV sphere: `cols` meridians, `bands` latitude bands -> 2*cols*(bands-1) triangles,
-    // the remainder made up by splitting triangles at their centroid (+2 each).
-    uint64_t cols = static_cast<uint64_t>(std::sqrt(static_cast<double>(target)));
-    if (cols < 3) cols = 3;
-    uint64_t bands = target / (2 * cols) + 1;
-    if (bands < 2) { bands = 2; cols = target / 2; }
-    while (2 * cols * (bands - 1) > target) bands--;
-    const uint64_t base = 2 * cols * (bands - 1);
+    // Cube-sphere: each cube face carries an n x n grid of quads (two triangles each),
+    // pushed out to a bumpy star-shaped surface -> 12 n^2 well-shaped triangles and no
+    // pole fans; the remainder is made up by splitting triangles at their centroid (+2 each).
+    uint64_t n = static_cast<uint64_t>(std::sqrt(static_cast<double>(target) / 12.0));
+    if (n < 1) n = 1;
+    while (12 * n * n > target) n--;
+    if (n < 1) { *err = "stand-in needs at least 22 triangles"; return RTX_ERR_INVALID; }
+    const uint64_t base = 12 * n * n;
     const uint64_t extra = (target - base) / 2;
+    if (extra > base) { *err = "stand-in: unsupported triangle count"; return RTX_ERR_INVALID; }
 
     // box: side = 2 * camera height, centred under the camera in x, around z = 0
     const double side = 2 * probe.camera_position[1];
@@ -65,49 +67,57 @@ int generate_standin(const std::string &preset, uint64_t n_triangles, uint64_t s
     const double kPi = 3.14159265358979323846;
     const double ph1 = 2 * kPi * unit(mix64(seed ^ 0x11)), ph2 = 2 * kPi * unit(mix64(seed ^ 0x22)),
                  ph3 = 2 * kPi * unit(mix64(seed ^ 0x33));
-    auto radius = [&](double theta, double phi, uint64_t vid) {
-        // theta in [0, pi] from the north pole, phi in [0, 2pi)
+    // A point of the cube surface has integer coordinates (a,b,c) in [0,n]^3 with one of
+    // them 0 or n; everything below is a function of that triple only, so the copies of a
+    // point that two or three faces share come out bit-identical (a closed surface).
+    auto surface_point = [&](uint64_t a, uint64_t b, uint64_t c, double out[3]) {
+        const double x = -1.0 + 2.0 * static_cast<double>(a) / static_cast<double>(n);
+        const double y = -1.0 + 2.0 * static_cast<double>(b) / static_cast<double>(n);
+        const double z = -1.0 + 2.0 * static_cast<double>(c) / static_cast<double>(n);
+        const double len = std::sqrt(x * x + y * y + z * z);
+        const double dx = x / len, dy = y / len, dz = z / len;
         double r = 1.0;
-        r += 0.22 * std::sin(3 * theta + ph1) * std::cos(2 * phi + ph2);
-        r += 0.10 * std::sin(9 * theta + ph2) * std::sin(7 * phi + ph3);
-        r += 0.035 * std::sin(31 * theta + ph3) * std::cos(29 * phi + ph1);
-        r += 0.010 * (unit(mix64(seed * 0x100000001B3ull + vid)) - 0.5);   // scan-like roughness
-        return r;
+        r += 0.22 * std::sin(3.0 * dy + ph1) * std::cos(2.5 * dx + ph2);
+        r += 0.10 * std::sin(8.0 * dx + ph2) * std::sin(7.0 * dz + ph3);
+        r += 0.035 * std::sin(27.0 * dy + ph3) * std::cos(23.0 * dz + ph1) * std::sin(19.0 * dx);
+        r += 0.010 * (unit(mix64(seed * 0x100000001B3ull + ((a * 2097152ull + b) * 2097152ull + c))) - 0.5);   // scan-like roughness
+        out[0] = r * dx; out[1] = r * dy; out[2] = r * dz;
     };
 
     std::vector<double> raw;   // model vertices before fitting
-    raw.reserve(3 * (cols * (bands - 1) + 2 + extra));
+    raw.reserve(3 * (6 * (n + 1) * (n + 1) + extra));
     auto push = [&](double x, double y, double z) { raw.push_back(x); raw.push_back(y); raw.push_back(z); };
-    // vertex 0 = north pole, then (bands-1) rings of `cols`, then the south pole
-    push(0, radius(0, 0, 0), 0);
-    for (uint64_t b = 1; b < bands; b++) {
-        const double theta = kPi * static_cast<double>(b) / static_cast<double>(bands);
-        for (uint64_t c = 0; c < cols; c++) {
-            const double phi = 2 * kPi * static_cast<double>(c) / static_cast<double>(cols);
-            const double r = radius(theta, phi, 1 + (b - 1) * cols + c);
-            push(r * std::sin(theta) * std::cos(phi), r * std::cos(theta), r * std::sin(theta) * std::sin(phi));
-        }
-    }
-    const uint64_t south = 1 + (bands - 1) * cols;
-    push(0, -radius(kPi, 0, south), 0);
-
     faces->clear();
     faces->reserve(3 * n_triangles);
     auto tri = [&](uint64_t a, uint64_t b, uint64_t c) {
         faces->push_back(static_cast<uint32_t>(a)); faces->push_back(static_cast<uint32_t>(b)); faces->push_back(static_cast<uint32_t>(c));
     };
-    auto ring = [&](uint64_t b, uint64_t c) { return 1 + (b - 1) * cols + (c % cols); };
-    for (uint64_t c = 0; c < cols; c++) tri(0, ring(1, c + 1), ring(1, c));
-    for (uint64_t b = 1; b + 1 < bands; b++)
-        for (uint64_t c = 0; c < cols; c++) {
-            tri(ring(b, c), ring(b, c + 1), ring(b + 1, c + 1));
-            tri(ring(b + 1, c + 1), ring(b + 1, c), ring(b, c));
-        }
-    for (uint64_t c = 0; c < cols; c++) tri(south, ring(bands - 1, c), ring(bands - 1, c + 1));
+    // face f: fixed axis f/2 at 0 (f even) or n (f odd); (i,j) run over the other two axes
+    for (int f = 0; f < 6; f++) {
+        const int axis = f / 2;
+        const uint64_t fixed = (f & 1) ? n : 0;
+        const uint64_t v0 = raw.size() / 3;
+        for (uint64_t j = 0; j <= n; j++)
+            for (uint64_t i = 0; i <= n; i++) {
+                uint64_t abc[3];
+                abc[axis] = fixed;
+                abc[(axis + 1) % 3] = i;
+                abc[(axis + 2) % 3] = j;
+                double p[3];
+                surface_point(abc[0], abc[1], abc[2], p);
+                push(p[0], p[1], p[2]);
+            }
+        for (uint64_t j = 0; j < n; j++)
+            for (uint64_t i = 0; i < n; i++) {
+                const uint64_t a = v0 + j * (n + 1) + i, b = a + 1, c = a + (n + 1), d = c + 1;
+                if (f & 1) { tri(a, b, d); tri(d, c, a); }      // outward winding on both sides of the axis
+                else       { tri(a, c, d); tri(d, b, a); }
+            }
+    }
     if (faces->size() / 3 != base) { *err = "stand-in: internal face count mismatch"; return RTX_ERR_INVALID; }
 
     // centroid splits, spread evenly over the base triangles
-    uint64_t next_vertex = south + 1;
+    uint64_t next_vertex = raw.size() / 3;
     for (uint64_t e = 0; e < extra; e++) {
         const uint64_t f = (e * base) / extra;
         uint32_t a = (*faces)[3 * f], b = (*faces)[3 * f + 1], c = (*faces)[3 * f + 2];

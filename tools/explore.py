@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Timing experiments on one GPU: knobs (environment, read per launch) x windows.  usage: tools/explore.py [scene] [mode]"""
+import os, sys, itertools
+sys.path.insert(0, os.getcwd())
+import torch
+import ray_tracer_amd as rt
+
+scene = sys.argv[1] if len(sys.argv) > 1 else "dragon"
+mode = rt.TRAVERSAL_PRUNED if (len(sys.argv) < 3 or sys.argv[2] == "pruned") else rt.TRAVERSAL_REFERENCE
+W, H = 3840, 2160
+host = rt.HostScene.load_obj("tests/golden/teapot.obj", "teapot") if scene == "teapot" else rt.HostScene.standin(scene)
+dev = rt.Scene(host)
+buf = torch.zeros(W * H * 3, dtype=torch.uint8, device="cuda")
+st = torch.cuda.current_stream().cuda_stream
+
+def timeit(p, n=3):
+    dev.render_device(p, rgb_u8=buf.data_ptr(), stream=st); torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); dev.render_device(p, rgb_u8=buf.data_ptr(), stream=st); b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    return min(ts)
+
+def run(label, env, **kw):
+    for k, v in env.items(): os.environ[k] = str(v)
+    p = rt.make_params(W, H, traversal=mode, **kw)
+    print(f"{label:50s} {timeit(p):8.3f} ms", flush=True)
+
+exps = sys.argv[3:] or ["chunk", "window", "weights", "tile"]
+if "chunk" in exps:
+    for ch in (64, 128, 256, 512, 1024):
+        run(f"chunk={ch}", {"RTX_CHUNK": ch, "RTX_W_INNER": 1, "RTX_W_LEAF": 1, "RTX_W_SHADE": 1})
+if "window" in exps:
+    os.environ["RTX_CHUNK"] = "1024"
+    run("window centre 1280x1280", {}, window=(1280, 2560, 440, 1720))
+    run("window centre 640x640", {}, window=(1600, 2240, 760, 1400))
+    run("window top-left 1280x440 (background)", {}, window=(0, 1280, 0, 440))
+if "weights" in exps:
+    for wi, wl, ws in ((1, 1, 1), (2, 1, 1), (1, 2, 2), (1, 4, 4), (4, 1, 1), (1, 2, 1), (1, 1, 2), (1, 8, 8), (2, 3, 3)):
+        for ch in (64, 256):
+            run(f"chunk={ch} weights inner/leaf/shade={wi}/{wl}/{ws}", {"RTX_CHUNK": ch, "RTX_W_INNER": wi, "RTX_W_LEAF": wl, "RTX_W_SHADE": ws})
+if "tile" in exps:
+    for t in (8, 16, 32, 64):
+        for ch in (64, 256):
+            run(f"tile={t} chunk={ch}", {"RTX_CHUNK": ch, "RTX_W_INNER": 1, "RTX_W_LEAF": 1, "RTX_W_SHADE": 1}, tile=(t, t))
