@@ -253,7 +253,8 @@ int rtx_scene_create_from_host(const rtx_host_scene *hs, int32_t device, rtx_sce
     const rtx::HostScene &s = hs->s;
     const uint64_t n = s.n_triangles(), m = s.nodes.size();
     if (n == 0 || m == 0) return fail(RTX_ERR_INVALID, "scene is empty");
-    if (m + 1 > 0xffffffffull) return fail(RTX_ERR_UNSUPPORTED, "too many BVH nodes");
+    // traversal-stack entries carry 28-bit triangle positions and node slots
+    if (m + 1 >= (1ull << 28) || n >= (1ull << 28)) return fail(RTX_ERR_UNSUPPORTED, "more than 2^28 triangles or BVH nodes");
 
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));

@@ -25,7 +25,7 @@ namespace {
 // second __launch_bounds__ argument of the render kernel: waves per SIMD the register
 // allocator must leave room for
 #ifndef RTX_WAVES_PER_EU
-#define RTX_WAVES_PER_EU 2
+#define RTX_WAVES_PER_EU 3
 #endif
 // include/common.hpp:12: DBL_EPSILON * 2^20 = 2^-32
 #define RTX_EPS (2.3283064365386962890625e-10)
@@ -264,16 +264,39 @@ __device__ __forceinline__ void start_query(Lane &L, const DevScene &sc, bool pr
     L.state = ST_INNER;
 }
 
+// A stack entry says where to continue without another trip to memory:
+//   bit 31 = 0: an inner node, bits 30..0 = slot of its left child
+//   bit 31 = 1: a leaf, bits 30..28 = count - 1 (1..7 triangles), bits 27..0 = first triangle
+//               position; the value 7 in bits 30..28 marks a bigger leaf, then bits 27..0
+//               hold the node's slot and its header is read.
+// (Triangle positions and node slots stay below 2^28; checked when the scene is created.)
+__device__ __forceinline__ uint32_t stack_entry(uint32_t slot, uint32_t first, uint32_t count) {
+    if (count == 0) return first;
+    if (count <= 7) return 0x80000000u | ((count - 1u) << 28) | first;
+    return 0xF0000000u | slot;
+}
+
 __device__ __forceinline__ void pop_node(Lane &L, const DevNode *nodes, const uint32_t *stack, uint32_t stride) {
     if (L.sp == 0) {
         L.state = ST_SHADE;
         return;
     }
     L.sp--;
-    const uint32_t slot = stack[L.sp * stride];
-    L.first = nodes[slot].first;
-    L.count = nodes[slot].count;
-    L.state = L.count ? ST_LEAF : ST_INNER;
+    const uint32_t e = stack[L.sp * stride];
+    if ((e & 0x80000000u) == 0) {
+        L.first = e;
+        L.count = 0;
+        L.state = ST_INNER;
+    } else if ((e >> 28) != 0xFu) {
+        L.first = e & 0x0FFFFFFFu;
+        L.count = ((e >> 28) & 7u) + 1u;
+        L.state = ST_LEAF;
+    } else {
+        const uint32_t slot = e & 0x0FFFFFFFu;
+        L.first = nodes[slot].first;
+        L.count = nodes[slot].count;
+        L.state = ST_LEAF;
+    }
 }
 
 template <bool PRUNE, bool STATS>
@@ -301,7 +324,7 @@ __device__ __forceinline__ void inner_step(Lane &L, const DevScene &sc, uint32_t
     const uint32_t af = A.first, ac = A.count, bf = B.first, bc = B.count;
     if (ha && hb) {
         const bool b_first = PRUNE && (tb < ta);
-        stack[L.sp * stride] = b_first ? L.first : L.first + 1;
+        stack[L.sp * stride] = b_first ? stack_entry(L.first, af, ac) : stack_entry(L.first + 1, bf, bc);
         L.sp++;
         L.first = b_first ? bf : af;
         L.count = b_first ? bc : ac;
