@@ -85,7 +85,10 @@ struct DevRender {
     double *t;
     unsigned long long *stats; // 9 counters, rtx_stats order
     uint32_t stack_stride;     // LDS stack entries per level (= block size)
-    uint32_t chunk;            // pixels of a tile one wave works through (multiple of 64)
+    // per-lane scratch (see Scratch in rtx_kernels.hip): field-major, `scratch_lanes` lanes per field
+    double *scratch_f64;
+    int32_t *scratch_i32;
+    uint64_t scratch_lanes;
     int32_t w_inner, w_leaf, w_shade;   // weights of the wave's step choice
     unsigned long long *wave_log;       // diagnostics: {start, end} 100 MHz ticks per wave, or NULL
 };

@@ -28,6 +28,9 @@ struct rtx_scene {
     int device = 0;
     rtx::DevScene dev{};
     void *d_nodes = nullptr, *d_tris = nullptr, *d_mats = nullptr, *d_lights = nullptr;
+    // per-lane scratch of the render kernel, kept between frames and grown on demand
+    void *d_scratch = nullptr;
+    uint64_t scratch_bytes = 0;
     uint64_t bytes = 0;
     uint64_t n_triangles = 0;
     std::mutex lock;
@@ -255,6 +258,8 @@ int rtx_scene_create_from_host(const rtx_host_scene *hs, int32_t device, rtx_sce
     if (n == 0 || m == 0) return fail(RTX_ERR_INVALID, "scene is empty");
     // traversal-stack entries carry 28-bit triangle positions and node slots
     if (m + 1 >= (1ull << 28) || n >= (1ull << 28)) return fail(RTX_ERR_UNSUPPORTED, "more than 2^28 triangles or BVH nodes");
+    // the kernel packs the light index of a shadow query into 16 bits
+    if (s.point_lights.size() + s.directional_lights.size() > 0xffff) return fail(RTX_ERR_UNSUPPORTED, "more than 65535 lights");
 
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -379,6 +384,7 @@ void rtx_scene_destroy(rtx_scene *sc) {
     (void)hipFree(sc->d_tris);
     (void)hipFree(sc->d_mats);
     (void)hipFree(sc->d_lights);
+    (void)hipFree(sc->d_scratch);
     delete sc;
 }
 
@@ -423,15 +429,12 @@ int rtx_render_device(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8,
     r.stats = (unsigned long long *)d_stats;
     // LDS stack: the largest block whose stack fits 64 KiB
     uint32_t block = 256;
-    while (block > 64 && rtx::render_lds_bytes(sc->dev.bvh_depth, r.depth, block) > 65536) block >>= 1;
-    if (rtx::render_lds_bytes(sc->dev.bvh_depth, r.depth, block) > 65536)
+    while (block > 64 && rtx::render_lds_bytes(sc->dev.bvh_depth, block) > 65536) block >>= 1;
+    if (rtx::render_lds_bytes(sc->dev.bvh_depth, block) > 65536)
         return fail(RTX_ERR_UNSUPPORTED, "BVH deeper than 255 levels: traversal stack does not fit LDS");
     r.stack_stride = block;
     // Tuning knobs of the wave scheduler (environment overrides are for experiments).
     auto knob = [](const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; };
-    int chunk = knob("RTX_CHUNK", 64);
-    if (chunk < 64) chunk = 64;
-    r.chunk = (uint32_t)(chunk / 64 * 64);
     r.w_inner = knob("RTX_W_INNER", 1);
     r.w_leaf = knob("RTX_W_LEAF", 2);
     r.w_shade = knob("RTX_W_SHADE", 2);
@@ -439,15 +442,28 @@ int rtx_render_device(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8,
     if (r.W == 0 || r.H == 0 || r.owned_tiles == 0) return RTX_OK;
     DeviceGuard guard(sc->device);
     if (!guard.ok) return fail(RTX_ERR_DEVICE, "cannot select the scene's device");
+    // Scratch: (4 + depth) doubles and (1 + 3*depth) ints per lane of the launch.  The buffer
+    // belongs to the scene handle (one render in flight per handle) and only ever grows.
+    {
+        const uint64_t need = rtx::render_scratch_bytes(r);
+        if (need > sc->scratch_bytes) {
+            if (sc->d_scratch) HIP_TRY(hipFree(sc->d_scratch));       // waits for launches still using it
+            sc->d_scratch = nullptr;
+            sc->scratch_bytes = 0;
+            HIP_TRY(hipMalloc(&sc->d_scratch, need));
+            sc->scratch_bytes = need;
+        }
+        r.scratch_lanes = rtx::render_scratch_lanes(r);
+        r.scratch_f64 = (double *)sc->d_scratch;
+        r.scratch_i32 = (int32_t *)((char *)sc->d_scratch + r.scratch_lanes * (4 + (uint64_t)r.depth) * 8);
+    }
     // Diagnostics: RTX_WAVE_LOG=<file> records every wave's start/end tick (100 MHz) of this
     // launch and writes them as raw u64 pairs.  Synchronous; never set in production.
     const char *log_path = getenv("RTX_WAVE_LOG");
     unsigned long long *d_log = nullptr;
     uint64_t n_waves = 0;
     if (log_path && *log_path) {
-        const uint64_t tile_pixels = (uint64_t)r.tile_w * r.tile_h;
-        n_waves = ((tile_pixels + r.chunk - 1) / r.chunk) * (uint64_t)r.owned_tiles;
-        n_waves = (n_waves + 3) / 4 * 4;
+        n_waves = (rtx::render_waves(r) + 3) / 4 * 4;
         HIP_TRY(hipMalloc((void **)&d_log, n_waves * 16));
         HIP_TRY(hipMemset(d_log, 0, n_waves * 16));
         r.wave_log = d_log;

@@ -12,10 +12,18 @@ namespace rtx {
 // must equal RTX_LAYOUT_PACKED_TILES in include/rtx.h (checked in rtx_api.cpp)
 constexpr int RTX_LAYOUT_PACKED_TILES_ = 1;
 
-// LDS bytes a render launch needs per block: one u32 traversal-stack slot per tree
-// level per lane, then 5 u32 (localColor r g b + reflectivity) per reflection level per lane.
-inline size_t render_lds_bytes(int32_t bvh_depth, int32_t ray_depth, uint32_t block_threads) {
-    return ((size_t)(bvh_depth + 1) + (size_t)ray_depth * 5) * block_threads * sizeof(uint32_t);
+// LDS bytes a render launch needs per block: one u32 traversal-stack slot per tree level per lane.
+inline size_t render_lds_bytes(int32_t bvh_depth, uint32_t block_threads) {
+    return (size_t)(bvh_depth + 1) * block_threads * sizeof(uint32_t);
+}
+// waves of a render launch: one per 8x8-pixel block of every owned tile
+inline uint64_t render_waves(const DevRender &rp) {
+    return (uint64_t)(rp.tile_w / 8) * (uint64_t)(rp.tile_h / 8) * (uint64_t)rp.owned_tiles;
+}
+// scratch a render launch needs: per lane (4 + depth) doubles and (1 + 3 * depth) ints
+inline uint64_t render_scratch_lanes(const DevRender &rp) { return (render_waves(rp) + 3) / 4 * 4 * 64; }
+inline uint64_t render_scratch_bytes(const DevRender &rp) {
+    return render_scratch_lanes(rp) * ((4 + (uint64_t)rp.depth) * 8 + (1 + 3 * (uint64_t)rp.depth) * 4);
 }
 
 hipError_t launch_render(const DevScene &sc, const DevRender &rp, bool prune, bool stats, uint32_t block_threads,

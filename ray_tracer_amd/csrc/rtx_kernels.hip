@@ -25,7 +25,7 @@ namespace {
 // second __launch_bounds__ argument of the render kernel: waves per SIMD the register
 // allocator must leave room for
 #ifndef RTX_WAVES_PER_EU
-#define RTX_WAVES_PER_EU 3
+#define RTX_WAVES_PER_EU 5
 #endif
 // include/common.hpp:12: DBL_EPSILON * 2^20 = 2^-32
 #define RTX_EPS (2.3283064365386962890625e-10)
@@ -63,11 +63,10 @@ __device__ __forceinline__ V3 ld3(const double *p) { return {p[0], p[1], p[2]}; 
 // range's ends (`ok`, checked per ray and per scene) or the divisor is zero (then
 // a / (+-0) = a * (+-inf) exactly, NaN for a = 0 included).
 struct RayDiv {
-    double nbx, nby, nbz;   // -r
     double yx, yy, yz;      // refined reciprocals (+-inf for a zero component)
-    bool zx, zy, zz;        // component == 0
-    bool ok;                // fast path valid for this ray
+    uint32_t flags;         // RD_ZX | RD_ZY | RD_ZZ: component == 0;  RD_OK: fast path valid for this ray
 };
+enum : uint32_t { RD_ZX = 1u, RD_ZY = 2u, RD_ZZ = 4u, RD_OK = 8u };
 
 __device__ __forceinline__ bool exp_safe(double v) {
     // 0, or 2^-300 <= |v| <= 2^300
@@ -85,19 +84,19 @@ __device__ __forceinline__ double refined_rcp(double b) {
 
 __device__ __forceinline__ RayDiv make_raydiv(V3 o, V3 r, bool scene_ok) {
     RayDiv d;
-    d.nbx = -r.x; d.nby = -r.y; d.nbz = -r.z;
-    d.zx = r.x == 0.0; d.zy = r.y == 0.0; d.zz = r.z == 0.0;
-    d.yx = d.zx ? __builtin_copysign(RTX_INF, r.x) : refined_rcp(r.x);
-    d.yy = d.zy ? __builtin_copysign(RTX_INF, r.y) : refined_rcp(r.y);
-    d.yz = d.zz ? __builtin_copysign(RTX_INF, r.z) : refined_rcp(r.z);
-    d.ok = scene_ok && exp_safe(o.x) && exp_safe(o.y) && exp_safe(o.z) && exp_safe(r.x) && exp_safe(r.y) && exp_safe(r.z);
+    const bool zx = r.x == 0.0, zy = r.y == 0.0, zz = r.z == 0.0;
+    d.yx = zx ? __builtin_copysign(RTX_INF, r.x) : refined_rcp(r.x);
+    d.yy = zy ? __builtin_copysign(RTX_INF, r.y) : refined_rcp(r.y);
+    d.yz = zz ? __builtin_copysign(RTX_INF, r.z) : refined_rcp(r.z);
+    const bool ok = scene_ok && exp_safe(o.x) && exp_safe(o.y) && exp_safe(o.z) && exp_safe(r.x) && exp_safe(r.y) && exp_safe(r.z);
+    d.flags = (zx ? RD_ZX : 0u) | (zy ? RD_ZY : 0u) | (zz ? RD_ZZ : 0u) | (ok ? RD_OK : 0u);
     return d;
 }
 
-// a / b given nb = -b, y = refined_rcp(b), zero = (b == 0)
-__device__ __forceinline__ double div_by(double a, double nb, double y, bool zero) {
+// a / b given y = refined_rcp(b), zero = (b == 0)
+__device__ __forceinline__ double div_by(double a, double b, double y, bool zero) {
     double q0 = a * y;
-    double rem = __builtin_fma(nb, q0, a);
+    double rem = __builtin_fma(-b, q0, a);
     double q1 = __builtin_fma(rem, y, q0);
     return zero ? q0 : q1;
 }
@@ -124,16 +123,17 @@ __device__ __forceinline__ bool slab(const double *lo, const double *hi, V3 o, V
 }
 
 // The same test with the divisions taken through RayDiv.
-__device__ __forceinline__ bool slab_fast(const double *lo, const double *hi, V3 o, const RayDiv &d, V3 lim, double *tnear,
+__device__ __forceinline__ bool slab_fast(const double *lo, const double *hi, V3 o, V3 r, const RayDiv &d, V3 lim, double *tnear,
                                           bool *beyond) {
-    double tx1 = div_by(lo[0] - o.x, d.nbx, d.yx, d.zx), tx2 = div_by(hi[0] - o.x, d.nbx, d.yx, d.zx);
+    const bool zx = d.flags & RD_ZX, zy = d.flags & RD_ZY, zz = d.flags & RD_ZZ;
+    double tx1 = div_by(lo[0] - o.x, r.x, d.yx, zx), tx2 = div_by(hi[0] - o.x, r.x, d.yx, zx);
     double nx = smin(tx1, tx2);
     double tmin = nx, tmax = smax(tx1, tx2);
-    double ty1 = div_by(lo[1] - o.y, d.nby, d.yy, d.zy), ty2 = div_by(hi[1] - o.y, d.nby, d.yy, d.zy);
+    double ty1 = div_by(lo[1] - o.y, r.y, d.yy, zy), ty2 = div_by(hi[1] - o.y, r.y, d.yy, zy);
     double ny = smin(ty1, ty2);
     tmin = smax(tmin, ny);
     tmax = smin(tmax, smax(ty1, ty2));
-    double tz1 = div_by(lo[2] - o.z, d.nbz, d.yz, d.zz), tz2 = div_by(hi[2] - o.z, d.nbz, d.yz, d.zz);
+    double tz1 = div_by(lo[2] - o.z, r.z, d.yz, zz), tz2 = div_by(hi[2] - o.z, r.z, d.yz, zz);
     double nz = smin(tz1, tz2);
     tmin = smax(tmin, nz);
     tmax = smin(tmax, smax(tz1, tz2));
@@ -160,6 +160,10 @@ struct Counters {
     unsigned long long v[9];
 };
 enum { C_PRIMARY, C_REFLECTION, C_SHADOW, C_OCCLUDED, C_CLOSEST, C_NODES, C_BOXHITS, C_LEAVES, C_TRIS };
+
+// Kept out of line: the inlined libm pow would raise the whole kernel's register count for a
+// term no shipped scene uses (specularity is 1 everywhere, scene.hpp:241).
+__device__ __attribute__((noinline)) double general_pow(double x, double e) { return pow(x, e); }
 
 __device__ __forceinline__ V3 reflect_ray(V3 ray, V3 n) {              // scene.hpp:185-187
     return sub(muls(smul(2.0, n), dot(n, ray)), ray);
@@ -198,64 +202,75 @@ __device__ __forceinline__ int clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 2
 // ---------------------------------------------------------------------------------
 // The render kernel.
 //
-// A wave owns a chunk of up to `chunk` pixels of one screen tile (8x8-pixel blocks in
-// row-major order, so the 64 lanes start on one block).  A lane carries one pixel at a
-// time through the reference's per-pixel work and then draws the next pixel of the
-// chunk, so lanes whose pixel was cheap (background) do not idle while neighbours
-// follow three reflections.
-//
-// The per-pixel work is cut into three kinds of step, and in every round the wave
-// runs ONE kind, the one most lanes are waiting for (ballot + popcount), instead of
-// running all kinds with the lanes that need them masked in turn:
+// One lane = one pixel, one wave = one 8x8-pixel block of a screen tile.  The per-pixel
+// work is cut into three kinds of step, and in every round the wave runs ONE kind, the
+// one most lanes are waiting for (ballot + popcount, weighted), instead of running all
+// kinds with the lanes that need them masked in turn:
 //   INNER  one BVH inner node: both children (one 128-byte line) slab-tested, far child
 //          pushed on the lane's LDS stack                      (bvh.hpp:197-208,213-234)
 //   LEAF   one triangle of a leaf                               (bvh.hpp:178-195, triangle.hpp:32-55)
 //   SHADE  a finished query: a closest-hit result starts the shadow query of the first
 //          light, a shadow result adds that light's term and starts the next light's
 //          query, the last one finishes the surface colour and either reflects or ends
-//          the pixel (scene.hpp:89-183); lanes without a pixel fetch one here.
+//          the pixel (scene.hpp:89-183).
 // BVH::intersectRay's recursion becomes this walk; its result is kept exactly:
 // smallest t with hit && tmin < t < tmax; equal t -> the triangle of the later leaf
 // (larger leaf `first`), inside one leaf the earlier triangle (bvh.hpp:186,204-208).
 //   PRUNE = false: a child is entered iff its slab test passes, shadow queries walk
 //           everything: exactly the reference's node visits.
-//   PRUNE = true : near child first; a child whose entry distance lies beyond the best
-//           hit so far (+ prune_margin) is skipped; a shadow query stops at its first
+//   PRUNE = true : near child first; a child entered later than the best hit so far
+//           (+ slack, see prune_limits) is skipped; a shadow query stops at its first
 //           accepted triangle.  Same results, less work.
-enum : int { ST_INNER = 0, ST_LEAF = 1, ST_SHADE = 2, ST_FETCH = 3, ST_DONE = 4 };
+//
+// Registers are what limits the waves per SIMD here (everything is FP64), so a lane
+// keeps only the running query in registers.  What a surface hit needs again after its
+// shadow queries (-ray, triangle, lighting sum) and the (localColor, reflectivity) pairs
+// that wait for their reflected colour (scene.hpp:122) live in a per-lane slice of a
+// global scratch buffer, written and read once per query in the SHADE step.
+enum : int { ST_INNER = 0, ST_LEAF = 1, ST_SHADE = 2, ST_DONE = 3 };
 
 struct Lane {
-    // current query
-    V3 o, r;
+    V3 o, r;             // the running query
     RayDiv rd;
-    double tmin, tmax, slack;
+    double slack;
     V3 lim;              // PRUNE: per-axis entry limits (prune_limits)
     double best_t;
     int32_t best_pos;
-    uint32_t best_leaf;
     uint32_t first, count, sp;
     int state;
-    // the surface hit being shaded and the pixel's path
-    int kind;            // 0 closest-hit query, 1 shadow query of light `li`
-    int d;               // reflections so far = entries waiting in the LDS blend stack
-    uint32_t li;
-    V3 v;                // -ray at the surface hit
-    int32_t pos;         // its triangle
-    double total;        // computeTotalLighting accumulator
-    // the pixel
-    int col, row, s;
-    uint32_t in_x, in_y;
-    int sum_r, sum_g, sum_b, first_r, first_g, first_b;
+    // kind (bit 0: 1 = shadow query), reflections so far d (bits 1..3), sample s (bits 4..15),
+    // light index li (bits 16..31)
+    uint32_t path;
+};
+__device__ __forceinline__ uint32_t path_kind(uint32_t p) { return p & 1u; }
+__device__ __forceinline__ uint32_t path_d(uint32_t p) { return (p >> 1) & 7u; }
+__device__ __forceinline__ uint32_t path_s(uint32_t p) { return (p >> 4) & 0xFFFu; }
+__device__ __forceinline__ uint32_t path_li(uint32_t p) { return p >> 16; }
+__device__ __forceinline__ uint32_t make_path(uint32_t kind, uint32_t d, uint32_t s, uint32_t li) {
+    return kind | (d << 1) | (s << 4) | (li << 16);
+}
+// tMin / tMax of the running query (src/main.cpp:83, scene.hpp:120,132,139,155)
+__device__ __forceinline__ double query_tmin(uint32_t p) { return (p & 0xFu) == 0u ? 1.0 : 0.001; }
+__device__ __forceinline__ double query_tmax(uint32_t p, uint32_t n_point) {
+    return (path_kind(p) == 1u && path_li(p) < n_point) ? 1.0 : RTX_INF;
+}
+
+// per-lane slice of the scratch buffer: field-major arrays of `n` lanes each
+struct Scratch {
+    double *f64;         // [0..2] -ray  [3] lighting sum  [4 + level] reflectivity
+    int32_t *i32;        // [0] triangle position  [1 + 3*level + c] localColor channel c
+    uint64_t n, id;
+    __device__ __forceinline__ double &f(uint32_t field) const { return f64[(uint64_t)field * n + id]; }
+    __device__ __forceinline__ int32_t &i(uint32_t field) const { return i32[(uint64_t)field * n + id]; }
 };
 
 __device__ __forceinline__ void start_query(Lane &L, const DevScene &sc, bool prune) {
     L.rd = make_raydiv(L.o, L.r, sc.fast_div_ok != 0);
     L.slack = prune ? slack_point(L.o, sc.scene_scale) : 0.0;
     // no accepted t can reach tmax, so tmax is the first limit
-    L.lim = prune ? prune_limits(L.tmax, L.slack, L.rd) : V3{RTX_INF, RTX_INF, RTX_INF};
+    L.lim = prune ? prune_limits(query_tmax(L.path, sc.n_point), L.slack, L.rd) : V3{RTX_INF, RTX_INF, RTX_INF};
     L.best_t = RTX_INF;
     L.best_pos = -1;
-    L.best_leaf = 0;
     // slot 0 holds a box no ray enters and slot 1 the root: the walk starts as the pair
     // test of (0, 1), which is the root's own slab test (bvh.hpp:174)
     L.first = 0;
@@ -306,9 +321,9 @@ __device__ __forceinline__ void inner_step(Lane &L, const DevScene &sc, uint32_t
     const DevNode &B = nodes[L.first + 1];
     double ta, tb;
     bool ha, hb, beyond_a, beyond_b;
-    if (L.rd.ok) {
-        ha = slab_fast(A.bmin, A.bmax, L.o, L.rd, L.lim, &ta, &beyond_a);
-        hb = slab_fast(B.bmin, B.bmax, L.o, L.rd, L.lim, &tb, &beyond_b);
+    if (L.rd.flags & RD_OK) {
+        ha = slab_fast(A.bmin, A.bmax, L.o, L.r, L.rd, L.lim, &ta, &beyond_a);
+        hb = slab_fast(B.bmin, B.bmax, L.o, L.r, L.rd, L.lim, &tb, &beyond_b);
     } else {   // ray components at the ends of the exponent range: plain divisions
         ha = slab(A.bmin, A.bmax, L.o, L.r, L.lim, &ta, &beyond_a);
         hb = slab(B.bmin, B.bmax, L.o, L.r, L.lim, &tb, &beyond_b);
@@ -348,16 +363,17 @@ __device__ __forceinline__ void leaf_step(Lane &L, const DevScene &sc, const uin
         if (L.first == tr.leaf_first) c.v[C_LEAVES]++;
     }
     double t;
-    if (tri_hit(tr, L.o, L.r, &t) && t > L.tmin && t < L.tmax) {
-        const uint32_t leaf = tr.leaf_first;
-        // equal t inside one leaf: the earlier triangle stays (strict <, bvh.hpp:186)
-        if (t < L.best_t || (t == L.best_t && leaf > L.best_leaf)) {
+    if (tri_hit(tr, L.o, L.r, &t) && t > query_tmin(L.path) && t < query_tmax(L.path, sc.n_point)) {
+        // equal t: the later leaf wins; inside one leaf the earlier triangle stays (strict <,
+        // bvh.hpp:186).  The best hit's leaf is read back only on an exact tie.
+        bool better = t < L.best_t;
+        if (t == L.best_t) better = tr.leaf_first > sc.tris[L.best_pos].leaf_first;
+        if (better) {
             L.best_t = t;
             L.best_pos = (int32_t)L.first;
-            L.best_leaf = leaf;
             if (PRUNE) {
                 L.lim = prune_limits(t, L.slack, L.rd);
-                if (L.kind == 1) {         // a shadow query only asks whether a hit exists
+                if (path_kind(L.path) == 1u) {   // a shadow query only asks whether a hit exists
                     L.state = ST_SHADE;
                     return;
                 }
@@ -370,14 +386,14 @@ __device__ __forceinline__ void leaf_step(Lane &L, const DevScene &sc, const uin
 }
 
 // src/main.cpp:78-83: camera ray of pixel (col,row), sample s
-__device__ __forceinline__ void primary_ray(Lane &L, const DevScene &sc, const DevRender &rp) {
+__device__ __forceinline__ void primary_ray(Lane &L, const DevScene &sc, const DevRender &rp, int col, int row, uint32_t s) {
     // putPixel inverted (src/main.cpp:90-94): row = -y + H/2 - 1, col = x + W/2
-    const int x = L.col - rp.W / 2, y = rp.H / 2 - 1 - L.row;
+    const int x = col - rp.W / 2, y = rp.H / 2 - 1 - row;
     double fx = (double)x, fy = (double)y;
-    if (L.s > 0) {   // samples > 0 add a jitter in [0,1)^2 (this build's extension)
-        const uint64_t k = (uint64_t)L.row * (uint64_t)rp.W + (uint64_t)L.col;
+    if (s > 0) {   // samples > 0 add a jitter in [0,1)^2 (this build's extension)
+        const uint64_t k = (uint64_t)row * (uint64_t)rp.W + (uint64_t)col;
         uint64_t z = splitmix64(splitmix64(rp.seed) ^ k);
-        z = splitmix64(z ^ ((uint64_t)(uint32_t)L.s << 32));
+        z = splitmix64(z ^ ((uint64_t)s << 32));
         fx = fx + (double)(z >> 32) * (1.0 / 4294967296.0);
         fy = fy + (double)(z & 0xFFFFFFFFull) * (1.0 / 4294967296.0);
     }
@@ -387,26 +403,29 @@ __device__ __forceinline__ void primary_ray(Lane &L, const DevScene &sc, const D
     V3 ry = {sc.cy * rx.x + sc.sy * rx.z, rx.y, (-sc.sy) * rx.x + sc.cy * rx.z};
     L.r = {sc.cz * ry.x - sc.sz * ry.y, sc.sz * ry.x + sc.cz * ry.y, ry.z};
     L.o = {sc.cam[0], sc.cam[1], sc.cam[2]};
-    L.tmin = 1.0;
-    L.tmax = RTX_INF;
-    L.kind = 0;
-    L.d = 0;
+    L.path = make_path(0, 0, s, 0);
 }
 
-// A finished query (scene.hpp:89-183).  Leaves the lane with a new query (ST_INNER) or
-// without a pixel (ST_FETCH).
+// What a pixel accumulates over its samples (only used when spp > 1).
+struct PixelSum {
+    int r, g, b;
+};
+
+// A finished query (scene.hpp:89-183).  Leaves the lane with a new query (ST_INNER) or done.
 template <bool PRUNE, bool STATS>
-__device__ __forceinline__ void shade_step(Lane &L, const DevScene &sc, const DevRender &rp, uint32_t *pend, uint32_t stride,
-                                           uint32_t local_tile, Counters &c) {
+__device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScene &sc, const DevRender &rp, const Scratch &scr,
+                                           int col, int row, uint64_t out, Counters &c) {
     const uint32_t n_lights = sc.n_point + sc.n_dir;
+    const uint32_t kind = path_kind(L.path), s = path_s(L.path);
+    uint32_t d = path_d(L.path), li = path_li(L.path);
     bool path_done = false;
     int cr = sc.bg[0], cg = sc.bg[1], cb = sc.bg[2];
     bool lights = false;
-    if (L.kind == 0) {
+    if (kind == 0) {
         // Scene::traceRay after the closest-hit query (scene.hpp:97-111)
-        if (STATS) c.v[L.d == 0 ? C_PRIMARY : C_REFLECTION]++;
-        if (L.d == 0 && L.s == 0) {
-            const uint64_t k = (uint64_t)L.row * (uint64_t)rp.W + (uint64_t)L.col;
+        if (STATS) c.v[d == 0 ? C_PRIMARY : C_REFLECTION]++;
+        if (d == 0 && s == 0) {
+            const uint64_t k = (uint64_t)row * (uint64_t)rp.W + (uint64_t)col;
             if (rp.hit) rp.hit[k] = (L.best_pos >= 0) ? (int32_t)sc.tris[L.best_pos].orig_id : -1;
             if (rp.t) rp.t[k] = L.best_t;
         }
@@ -415,149 +434,152 @@ __device__ __forceinline__ void shade_step(Lane &L, const DevScene &sc, const De
         } else {
             if (STATS) c.v[C_CLOSEST]++;
             L.o = add(L.o, smul(L.best_t, L.r));                        // point, scene.hpp:105
-            L.v = muls(L.r, -1.0);                                      // -ray, vector3.hpp:108-110
-            L.pos = L.best_pos;
-            L.total = sc.ambient;                                       // scene.hpp:128
-            L.li = 0;
+            const V3 v = muls(L.r, -1.0);                               // -ray, vector3.hpp:108-110
+            scr.f(0) = v.x; scr.f(1) = v.y; scr.f(2) = v.z;
+            scr.f(3) = sc.ambient;                                      // scene.hpp:128
+            scr.i(0) = L.best_pos;
+            li = 0;
             lights = true;
         }
     } else {
         // the rest of Scene::computeLighting (scene.hpp:159-182) with light = r, point = o
         if (STATS) { c.v[C_SHADOW]++; if (L.best_pos >= 0) c.v[C_OCCLUDED]++; }
         if (L.best_pos < 0) {
-            const V3 n = ld3(sc.tris[L.pos].n);
-            const int spec = sc.mats[L.pos].specularity;
-            const double intensity = sc.lights[L.li].intensity;
+            const int32_t pos = scr.i(0);
+            const V3 n = ld3(sc.tris[pos].n);
+            const V3 v = {scr.f(0), scr.f(1), scr.f(2)};
+            const int spec = sc.mats[pos].specularity;
+            const double intensity = sc.lights[li].intensity;
             double term = 0.0;
             const double nl = dot(n, L.r);
             if (nl > 0.0) term += intensity * (nl / (mag(n) * mag(L.r)));
+            __builtin_amdgcn_sched_barrier(0);
             if (spec != -1) {
                 const V3 R = reflect_ray(L.r, n);
-                const double rv = dot(R, L.v);
+                const double rv = dot(R, v);
                 if (rv > 0) {
-                    const double cosv = rv / (mag(R) * mag(L.v));
+                    const double cosv = rv / (mag(R) * mag(v));
                     // pow(x, 1) is x exactly in every libm; other exponents go through the
                     // device pow, which may differ from glibc's in the last place
-                    term += intensity * ((spec == 1) ? cosv : pow(cosv, (double)spec));
+                    term += intensity * ((spec == 1) ? cosv : general_pow(cosv, (double)spec));
                 }
             }
-            L.total += term;
+            scr.f(3) += term;
         }
-        L.li++;
+        li++;
         lights = true;
     }
+    __builtin_amdgcn_sched_barrier(0);
     if (lights) {
-        if (L.li < n_lights) {
+        if (li < n_lights) {
             // computeTotalLighting (scene.hpp:130-142): point lights first (light = position -
             // point, tMax = 1), then directional ones (light = direction, tMax = inf)
-            const bool is_point = L.li < sc.n_point;
-            const V3 lv = ld3(sc.lights[L.li].v);
-            L.r = is_point ? sub(lv, L.o) : lv;
-            L.tmin = 0.001;
-            L.tmax = is_point ? 1.0 : RTX_INF;
-            L.kind = 1;
+            const V3 lv = ld3(sc.lights[li].v);
+            L.r = (li < sc.n_point) ? sub(lv, L.o) : lv;
+            L.path = make_path(1, d, s, li);
             start_query(L, sc, PRUNE);
             return;
         }
         // Color * double truncates each channel (color.hpp:47-53)
-        const DevMat &mt = sc.mats[L.pos];
-        const int lr = (int)(mt.color[0] * L.total), lg = (int)(mt.color[1] * L.total), lb = (int)(mt.color[2] * L.total);
+        const int32_t pos = scr.i(0);
+        const DevMat &mt = sc.mats[pos];
+        const double total = scr.f(3);
+        const int lr = (int)(mt.color[0] * total), lg = (int)(mt.color[1] * total), lb = (int)(mt.color[2] * total);
         const double refl = mt.reflectivity;
-        if (L.d == rp.depth || refl < 0) {                              // scene.hpp:115-117
+        if (d == (uint32_t)rp.depth || refl < 0) {                      // scene.hpp:115-117
             cr = lr; cg = lg; cb = lb;
             path_done = true;
         } else {
-            uint32_t *e = pend + (uint32_t)L.d * 5u * stride;
-            e[0] = (uint32_t)lr; e[stride] = (uint32_t)lg; e[2 * stride] = (uint32_t)lb;
-            e[3 * stride] = (uint32_t)__double2loint(refl); e[4 * stride] = (uint32_t)__double2hiint(refl);
-            L.d++;
-            L.r = reflect_ray(L.v, ld3(sc.tris[L.pos].n));              // scene.hpp:119
-            L.tmin = 0.001;
-            L.tmax = RTX_INF;
-            L.kind = 0;
+            scr.i(1 + 3 * d) = lr; scr.i(2 + 3 * d) = lg; scr.i(3 + 3 * d) = lb;
+            scr.f(4 + d) = refl;
+            const V3 v = {scr.f(0), scr.f(1), scr.f(2)};
+            L.r = reflect_ray(v, ld3(sc.tris[pos].n));                  // scene.hpp:119
+            L.path = make_path(0, d + 1, s, 0);
             start_query(L, sc, PRUNE);
             return;
         }
     }
     if (!path_done) return;
     // localColor * (1 - reflectivity) + reflectedColor * reflectivity (scene.hpp:122), innermost first
-    while (L.d > 0) {
-        L.d--;
-        const uint32_t *e = pend + (uint32_t)L.d * 5u * stride;
-        const int lr = (int)e[0], lg = (int)e[stride], lb = (int)e[2 * stride];
-        const double refl = __hiloint2double((int)e[4 * stride], (int)e[3 * stride]);
+    while (d > 0) {
+        d--;
+        const int lr = scr.i(1 + 3 * d), lg = scr.i(2 + 3 * d), lb = scr.i(3 + 3 * d);
+        const double refl = scr.f(4 + d);
         const double keep = 1 - refl;
         cr = (int)(lr * keep) + (int)(cr * refl);
         cg = (int)(lg * keep) + (int)(cg * refl);
         cb = (int)(lb * keep) + (int)(cb * refl);
     }
-    if (L.s == 0) { L.first_r = cr; L.first_g = cg; L.first_b = cb; }
-    L.sum_r += clamp255(cr); L.sum_g += clamp255(cg); L.sum_b += clamp255(cb);
-    L.s++;
-    if (L.s < rp.spp) {
-        primary_ray(L, sc, rp);
+    // putPixel (src/main.cpp:90-94) + the clamp of saveCanvas (src/main.cpp:107)
+    if (rp.spp == 1) {
+        if (rp.rgb) {
+            rp.rgb[3 * out + 0] = (uint8_t)clamp255(cr);
+            rp.rgb[3 * out + 1] = (uint8_t)clamp255(cg);
+            rp.rgb[3 * out + 2] = (uint8_t)clamp255(cb);
+        }
+        if (rp.rgb_i32) { rp.rgb_i32[3 * out + 0] = cr; rp.rgb_i32[3 * out + 1] = cg; rp.rgb_i32[3 * out + 2] = cb; }
+        L.state = ST_DONE;
+        return;
+    }
+    acc.r += clamp255(cr); acc.g += clamp255(cg); acc.b += clamp255(cb);
+    if (s + 1 < (uint32_t)rp.spp) {
+        primary_ray(L, sc, rp, col, row, s + 1);
         start_query(L, sc, PRUNE);
         return;
     }
-    // putPixel (src/main.cpp:90-94) + the clamp of saveCanvas (src/main.cpp:107)
-    uint64_t out = (uint64_t)L.row * (uint64_t)rp.W + (uint64_t)L.col;
-    if (rp.layout == RTX_LAYOUT_PACKED_TILES_)
-        out = ((uint64_t)local_tile * (uint32_t)rp.tile_h + L.in_y) * (uint32_t)rp.tile_w + L.in_x;
+    const int spp = rp.spp;
     if (rp.rgb) {
-        const int spp = rp.spp;
-        rp.rgb[3 * out + 0] = (uint8_t)((L.sum_r + spp / 2) / spp);
-        rp.rgb[3 * out + 1] = (uint8_t)((L.sum_g + spp / 2) / spp);
-        rp.rgb[3 * out + 2] = (uint8_t)((L.sum_b + spp / 2) / spp);
+        rp.rgb[3 * out + 0] = (uint8_t)((acc.r + spp / 2) / spp);
+        rp.rgb[3 * out + 1] = (uint8_t)((acc.g + spp / 2) / spp);
+        rp.rgb[3 * out + 2] = (uint8_t)((acc.b + spp / 2) / spp);
     }
-    if (rp.rgb_i32) {
-        rp.rgb_i32[3 * out + 0] = rp.spp == 1 ? L.first_r : L.sum_r;
-        rp.rgb_i32[3 * out + 1] = rp.spp == 1 ? L.first_g : L.sum_g;
-        rp.rgb_i32[3 * out + 2] = rp.spp == 1 ? L.first_b : L.sum_b;
-    }
-    L.state = ST_FETCH;
+    if (rp.rgb_i32) { rp.rgb_i32[3 * out + 0] = acc.r; rp.rgb_i32[3 * out + 1] = acc.g; rp.rgb_i32[3 * out + 2] = acc.b; }
+    L.state = ST_DONE;
 }
 
 template <bool PRUNE, bool STATS>
 __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const DevScene sc, const DevRender rp) {
     extern __shared__ uint32_t lds[];
+    const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t waves_per_block = blockDim.x >> 6;
-    const uint32_t blocks_x = (uint32_t)rp.tile_w >> 3;
-    const uint32_t tile_pixels = (uint32_t)rp.tile_w * (uint32_t)rp.tile_h;
-    const uint32_t chunks_per_tile = (tile_pixels + rp.chunk - 1) / rp.chunk;
+    const uint32_t blocks_x = (uint32_t)rp.tile_w >> 3, blocks_y = (uint32_t)rp.tile_h >> 3;
+    const uint32_t per_tile = blocks_x * blocks_y;
     const uint64_t gw = (uint64_t)blockIdx.x * waves_per_block + wave;
-    const uint32_t local_tile = (uint32_t)(gw / chunks_per_tile);
+    const uint32_t local_tile = (uint32_t)(gw / per_tile);
+    const uint32_t wb = (uint32_t)(gw % per_tile);
     if (local_tile >= (uint32_t)rp.owned_tiles) return;
-    const uint32_t tile = (rp.tile_count > 1) ? local_tile * (uint32_t)rp.tile_count + (uint32_t)rp.tile_rank : local_tile;
-    const uint32_t tile_x0 = (tile % (uint32_t)rp.tiles_x) * (uint32_t)rp.tile_w;
-    const uint32_t tile_y0 = (tile / (uint32_t)rp.tiles_x) * (uint32_t)rp.tile_h;
-    // pixel slots [slot_next, slot_end) of the tile belong to this wave (wave-uniform)
-    uint32_t slot_next = (uint32_t)(gw % chunks_per_tile) * rp.chunk;
-    const uint32_t slot_end = min(slot_next + rp.chunk, tile_pixels);
-
     const unsigned long long wave_t0 = rp.wave_log ? wall_clock64() : 0;
+    const uint32_t tile = (rp.tile_count > 1) ? local_tile * (uint32_t)rp.tile_count + (uint32_t)rp.tile_rank : local_tile;
+    const uint32_t tx = tile % (uint32_t)rp.tiles_x, ty = tile / (uint32_t)rp.tiles_x;
+    const uint32_t in_x = (wb % blocks_x) * 8u + (lane & 7u), in_y = (wb / blocks_x) * 8u + (lane >> 3);
+    const int col = (int)(tx * (uint32_t)rp.tile_w + in_x), row = (int)(ty * (uint32_t)rp.tile_h + in_y);
+    uint64_t out = (uint64_t)row * (uint64_t)rp.W + (uint64_t)col;
+    if (rp.layout == RTX_LAYOUT_PACKED_TILES_)
+        out = ((uint64_t)local_tile * (uint32_t)rp.tile_h + in_y) * (uint32_t)rp.tile_w + in_x;
+
     const uint32_t stride = rp.stack_stride;
     uint32_t *stack = lds + threadIdx.x;
-    uint32_t *pend = lds + (uint32_t)(sc.bvh_depth + 1) * stride + threadIdx.x;   // [level][5][lane]
+    const Scratch scr = {rp.scratch_f64, rp.scratch_i32, rp.scratch_lanes, gw * 64u + lane};
     Counters c;
     if (STATS) for (int i = 0; i < 9; i++) c.v[i] = 0;
 
     Lane L;
-    L.state = ST_FETCH;
-    L.kind = 0; L.d = 0; L.li = 0; L.pos = -1; L.total = 0.0; L.v = {0, 0, 0};
-    L.o = {0, 0, 0}; L.r = {0, 0, 1};
-    L.first = 0; L.count = 0; L.sp = 0;
-    L.best_t = RTX_INF; L.best_pos = -1; L.best_leaf = 0;
-    L.tmin = 0; L.tmax = 0; L.slack = 0; L.lim = {0, 0, 0};
-    L.col = 0; L.row = 0; L.s = 0; L.in_x = 0; L.in_y = 0;
-    L.sum_r = L.sum_g = L.sum_b = L.first_r = L.first_g = L.first_b = 0;
-    L.rd = make_raydiv(L.o, L.r, false);
+    PixelSum acc = {0, 0, 0};
+    L.state = ST_DONE;
+    L.best_t = RTX_INF; L.best_pos = -1; L.first = 0; L.count = 0; L.sp = 0; L.slack = 0; L.lim = {0, 0, 0};
+    L.o = {0, 0, 0}; L.r = {0, 0, 1}; L.path = 0;
+    L.rd = RayDiv{0, 0, 0, 0};
+    if (col >= rp.x0 && col < rp.x1 && row >= rp.y0 && row < rp.y1) {
+        primary_ray(L, sc, rp, col, row, 0);
+        start_query(L, sc, PRUNE);
+    }
 
     for (;;) {
         const unsigned long long m_inner = __ballot(L.state == ST_INNER);
         const unsigned long long m_leaf = __ballot(L.state == ST_LEAF);
-        const unsigned long long m_shade = __ballot(L.state == ST_SHADE || L.state == ST_FETCH);
-        if ((m_inner | m_leaf | m_shade) == 0) break;                   // every lane ST_DONE
+        const unsigned long long m_shade = __ballot(L.state == ST_SHADE);
+        if ((m_inner | m_leaf | m_shade) == 0) break;                   // every lane done
         // wave-uniform choice: the kind of step most lanes wait for (weighted)
         const int w_inner = __popcll(m_inner) * rp.w_inner, w_leaf = __popcll(m_leaf) * rp.w_leaf,
                   w_shade = __popcll(m_shade) * rp.w_shade;
@@ -566,39 +588,14 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
         } else if (w_leaf >= w_shade) {
             if (L.state == ST_LEAF) leaf_step<PRUNE, STATS>(L, sc, stack, stride, c);
         } else {
-            if (L.state == ST_SHADE) shade_step<PRUNE, STATS>(L, sc, rp, pend, stride, local_tile, c);
-            // lanes without a pixel draw the next slots of the chunk, in lane order
-            const unsigned long long need = __ballot(L.state == ST_FETCH);
-            if (need) {
-                if (L.state == ST_FETCH) {
-                    const uint32_t lane = threadIdx.x & 63u;
-                    const uint32_t slot = slot_next + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-                    if (slot >= slot_end) {
-                        L.state = ST_DONE;
-                    } else {
-                        const uint32_t blk = slot >> 6, in = slot & 63u;
-                        L.in_x = (blk % blocks_x) * 8u + (in & 7u);
-                        L.in_y = (blk / blocks_x) * 8u + (in >> 3);
-                        L.col = (int)(tile_x0 + L.in_x);
-                        L.row = (int)(tile_y0 + L.in_y);
-                        // outside the frame or the window: nothing to render, fetch again next time
-                        if (L.col >= rp.x0 && L.col < rp.x1 && L.row >= rp.y0 && L.row < rp.y1) {
-                            L.s = 0;
-                            L.sum_r = L.sum_g = L.sum_b = 0;
-                            primary_ray(L, sc, rp);
-                            start_query(L, sc, PRUNE);
-                        }
-                    }
-                }
-                slot_next += (uint32_t)__popcll(need);
-            }
+            if (L.state == ST_SHADE) shade_step<PRUNE, STATS>(L, acc, sc, rp, scr, col, row, out, c);
         }
     }
     if (STATS && rp.stats) {
         for (int i = 0; i < 9; i++)
             if (c.v[i]) atomicAdd(&rp.stats[i], c.v[i]);
     }
-    if (rp.wave_log && (threadIdx.x & 63u) == 0) {
+    if (rp.wave_log && lane == 0) {
         rp.wave_log[2 * gw] = wave_t0;
         rp.wave_log[2 * gw + 1] = wall_clock64();
     }
@@ -622,11 +619,11 @@ __global__ void __launch_bounds__(256) divtest_kernel(uint64_t seed, uint64_t n,
     if (i % 97 == 96) a = (i & 128) ? 0.0 : -0.0;
     V3 r = {b, 1.0, 1.0}, o = {0, 0, 0};
     RayDiv d = make_raydiv(o, r, true);
-    double q = div_by(a, d.nbx, d.yx, d.zx);
+    double q = div_by(a, b, d.yx, (d.flags & RD_ZX) != 0);
     double ref = a / b;
     unsigned long long qb = (unsigned long long)__double_as_longlong(q), rb = (unsigned long long)__double_as_longlong(ref);
     bool same = qb == rb || (q != q && ref != ref) || (q == 0.0 && ref == 0.0);   // NaN payload / sign of zero are free
-    if (!d.ok || !same) atomicAdd(mismatches, 1ull);
+    if (!(d.flags & RD_OK) || !same) atomicAdd(mismatches, 1ull);
 }
 
 // [rank][local tile][tile_h][tile_w][bpp] -> row-major frame
@@ -647,15 +644,13 @@ __global__ void __launch_bounds__(256) untile_kernel(const uint8_t *__restrict__
 
 hipError_t launch_render(const DevScene &sc, const DevRender &rp, bool prune, bool stats, uint32_t block_threads,
                          hipStream_t st) {
-    const uint64_t tile_pixels = (uint64_t)rp.tile_w * (uint64_t)rp.tile_h;
-    const uint64_t chunks_per_tile = (tile_pixels + rp.chunk - 1) / rp.chunk;
-    const uint64_t waves = chunks_per_tile * (uint64_t)rp.owned_tiles;
+    const uint64_t waves = render_waves(rp);
     if (waves == 0) return hipSuccess;
     const uint32_t wpb = block_threads / 64;
     const uint64_t blocks = (waves + wpb - 1) / wpb;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     dim3 grid((uint32_t)blocks), block(block_threads);
-    const size_t lds = render_lds_bytes(sc.bvh_depth, rp.depth, block_threads);
+    const size_t lds = render_lds_bytes(sc.bvh_depth, block_threads);
     if (prune && stats) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, lds, st, sc, rp);
     else if (prune) hipLaunchKernelGGL((render_kernel<true, false>), grid, block, lds, st, sc, rp);
     else if (stats) hipLaunchKernelGGL((render_kernel<false, true>), grid, block, lds, st, sc, rp);
