@@ -156,6 +156,10 @@ typedef struct rtx_render_params {
 typedef struct rtx_stats {
     uint64_t primary_rays, reflection_rays, shadow_rays, shadow_occluded, closest_hits;
     uint64_t node_visits, box_hits, leaf_visits, triangle_tests;
+    /* scheduling of the render kernel: rounds a wave ran of each step kind (0 inner node pair,
+     * 1 leaf triangle, 2 shading) summed over waves, and the lanes that took part in them;
+     * lane_steps / (64 * rounds) is the lane utilisation of that kind of step */
+    uint64_t rounds[3], lane_steps[3];
     double kernel_ms;            /* HIP-event time of the render kernel(s)                    */
 } rtx_stats;
 
@@ -175,7 +179,8 @@ int rtx_render(rtx_scene *scene, const rtx_render_params *p, uint8_t *rgb_out, i
 /* Same frame into DEVICE buffers, asynchronous on `stream` (a hipStream_t, NULL =
  * default stream).  d_rgb_i32 (nullable): the unclamped Color ints, 3 per pixel
  * (the reference's canvas, src/main.cpp:16); d_t (nullable): primary closestT.
- * d_stats (nullable): device pointer to an rtx_stats the kernel adds into. */
+ * d_stats (nullable): device pointer to the 15 uint64 counters of rtx_stats (everything
+ * before kernel_ms) that the kernel adds into. */
 int rtx_render_device(rtx_scene *scene, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id,
                       void *d_rgb_i32, void *d_t, void *d_stats, void *stream);
 

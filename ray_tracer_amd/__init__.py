@@ -78,16 +78,23 @@ class RenderParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "primary_rays", "reflection_rays", "shadow_rays", "shadow_occluded", "closest_hits",
-        "node_visits", "box_hits", "leaf_visits", "triangle_tests")] + [("kernel_ms", C.c_double)]
+        "node_visits", "box_hits", "leaf_visits", "triangle_tests")] + [
+        ("rounds", C.c_uint64 * 3), ("lane_steps", C.c_uint64 * 3), ("kernel_ms", C.c_double)]
 
     @property
     def rays(self) -> int:
         return self.primary_rays + self.reflection_rays + self.shadow_rays
 
     def as_dict(self) -> dict:
-        d = {n: getattr(self, n) for n, _ in self._fields_}
+        d = {n: getattr(self, n) for n, _ in self._fields_ if n not in ("rounds", "lane_steps")}
         d["rays"] = self.rays
         return d
+
+    def scheduling(self) -> dict:
+        """Rounds per step kind and the lane utilisation of each."""
+        names = ("inner", "leaf", "shade")
+        return {n: {"rounds": int(self.rounds[i]), "lane_util": (self.lane_steps[i] / (64.0 * self.rounds[i])) if self.rounds[i] else 0.0}
+                for i, n in enumerate(names)}
 
 
 # every symbol include/rtx.h declares

@@ -83,13 +83,16 @@ struct DevRender {
     int32_t *hit;
     int32_t *rgb_i32;
     double *t;
-    unsigned long long *stats; // 9 counters, rtx_stats order
+    unsigned long long *stats; // 15 counters, rtx_stats order
     uint32_t stack_stride;     // LDS stack entries per level (= block size)
     // per-lane scratch (see Scratch in rtx_kernels.hip): field-major, `scratch_lanes` lanes per field
     double *scratch_f64;
     int32_t *scratch_i32;
     uint64_t scratch_lanes;
+    uint32_t *work;            // next 8x8 block to hand out (zeroed before every launch)
+    uint32_t total_blocks;     // 8x8 blocks of this launch
     int32_t w_inner, w_leaf, w_shade;   // weights of the wave's step choice
+    uint32_t xcd_group;                 // blocks per XCD-local run (0 = plain block order)
     unsigned long long *wave_log;       // diagnostics: {start, end} 100 MHz ticks per wave, or NULL
 };
 

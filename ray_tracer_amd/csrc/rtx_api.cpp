@@ -33,6 +33,7 @@ struct rtx_scene {
     uint64_t scratch_bytes = 0;
     uint64_t bytes = 0;
     uint64_t n_triangles = 0;
+    int cu_count = 256;
     std::mutex lock;
 };
 
@@ -313,6 +314,10 @@ int rtx_scene_create_from_host(const rtx_host_scene *hs, int32_t device, rtx_sce
     if (!sc) return fail(RTX_ERR_NOMEM, "out of host memory");
     sc->device = device;
     sc->n_triangles = n;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) sc->cu_count = cus;
+    }
     auto upload = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
         if (e != hipSuccess) return e;
@@ -433,8 +438,9 @@ int rtx_render_device(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8,
     if (rtx::render_lds_bytes(sc->dev.bvh_depth, block) > 65536)
         return fail(RTX_ERR_UNSUPPORTED, "BVH deeper than 255 levels: traversal stack does not fit LDS");
     r.stack_stride = block;
-    // Tuning knobs of the wave scheduler (environment overrides are for experiments).
+    // Tuning knobs (environment overrides are for experiments).
     auto knob = [](const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; };
+    r.xcd_group = (uint32_t)knob("RTX_XCD_GROUP", 0);
     r.w_inner = knob("RTX_W_INNER", 1);
     r.w_leaf = knob("RTX_W_LEAF", 2);
     r.w_shade = knob("RTX_W_SHADE", 2);
@@ -442,10 +448,20 @@ int rtx_render_device(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8,
     if (r.W == 0 || r.H == 0 || r.owned_tiles == 0) return RTX_OK;
     DeviceGuard guard(sc->device);
     if (!guard.ok) return fail(RTX_ERR_DEVICE, "cannot select the scene's device");
-    // Scratch: (4 + depth) doubles and (1 + 3*depth) ints per lane of the launch.  The buffer
-    // belongs to the scene handle (one render in flight per handle) and only ever grows.
+    // Persistent launch: as many blocks as the chip keeps resident (RTX_WAVES_PER_EU waves per
+    // SIMD = that many 256-thread blocks per CU), never more than there are 8x8 blocks of work.
+    const uint64_t total_blocks = rtx::render_waves(r);
+    if (total_blocks >= (1ull << 26)) return fail(RTX_ERR_UNSUPPORTED, "more than 2^32 pixels in one launch");
+    r.total_blocks = (uint32_t)total_blocks;
+    const uint32_t wpb = block / 64;
+    uint64_t resident = (uint64_t)sc->cu_count * (uint64_t)knob("RTX_BLOCKS_PER_CU", 5) * (256 / block);
+    uint64_t grid_blocks = (total_blocks + wpb - 1) / wpb;
+    if (grid_blocks > resident) grid_blocks = resident;
+    // Scratch: a work counter, then (4 + depth) doubles and (1 + 3*depth) ints per resident lane.
+    // The buffer belongs to the scene handle (one render in flight per handle) and only grows.
     {
-        const uint64_t need = rtx::render_scratch_bytes(r);
+        const uint64_t lanes = grid_blocks * block;
+        const uint64_t need = rtx::render_scratch_bytes(lanes, r.depth);
         if (need > sc->scratch_bytes) {
             if (sc->d_scratch) HIP_TRY(hipFree(sc->d_scratch));       // waits for launches still using it
             sc->d_scratch = nullptr;
@@ -453,9 +469,11 @@ int rtx_render_device(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8,
             HIP_TRY(hipMalloc(&sc->d_scratch, need));
             sc->scratch_bytes = need;
         }
-        r.scratch_lanes = rtx::render_scratch_lanes(r);
-        r.scratch_f64 = (double *)sc->d_scratch;
-        r.scratch_i32 = (int32_t *)((char *)sc->d_scratch + r.scratch_lanes * (4 + (uint64_t)r.depth) * 8);
+        r.work = (uint32_t *)sc->d_scratch;
+        r.scratch_lanes = lanes;
+        r.scratch_f64 = (double *)((char *)sc->d_scratch + 256);
+        r.scratch_i32 = (int32_t *)((char *)r.scratch_f64 + lanes * (4 + (uint64_t)r.depth) * 8);
+        HIP_TRY(hipMemsetAsync(r.work, 0, 256, (hipStream_t)stream));
     }
     // Diagnostics: RTX_WAVE_LOG=<file> records every wave's start/end tick (100 MHz) of this
     // launch and writes them as raw u64 pairs.  Synchronous; never set in production.
@@ -463,12 +481,13 @@ int rtx_render_device(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8,
     unsigned long long *d_log = nullptr;
     uint64_t n_waves = 0;
     if (log_path && *log_path) {
-        n_waves = (rtx::render_waves(r) + 3) / 4 * 4;
+        n_waves = grid_blocks * wpb;
         HIP_TRY(hipMalloc((void **)&d_log, n_waves * 16));
         HIP_TRY(hipMemset(d_log, 0, n_waves * 16));
         r.wave_log = d_log;
     }
-    HIP_TRY(rtx::launch_render(sc->dev, r, p->traversal == RTX_TRAVERSAL_PRUNED, d_stats != nullptr, block, (hipStream_t)stream));
+    HIP_TRY(rtx::launch_render(sc->dev, r, p->traversal == RTX_TRAVERSAL_PRUNED, d_stats != nullptr, block, (uint32_t)grid_blocks,
+                               (hipStream_t)stream));
     if (d_log) {
         std::vector<unsigned long long> h(n_waves * 2);
         HIP_TRY(hipMemcpy(h.data(), d_log, n_waves * 16, hipMemcpyDeviceToHost));
@@ -505,7 +524,7 @@ int rtx_render(rtx_scene *sc, const rtx_render_params *p, uint8_t *rgb_out, int3
     HIP_TRY_C(hipMalloc(&d_rgb, px * 3));
     HIP_TRY_C(hipMemset(d_rgb, 0, px * 3));
     if (hit_id_out) { HIP_TRY_C(hipMalloc(&d_hit, px * 4)); HIP_TRY_C(hipMemset(d_hit, 0xff, px * 4)); }
-    if (stats) { HIP_TRY_C(hipMalloc(&d_stats, 9 * 8)); HIP_TRY_C(hipMemset(d_stats, 0, 9 * 8)); }
+    if (stats) { HIP_TRY_C(hipMalloc(&d_stats, 15 * 8)); HIP_TRY_C(hipMemset(d_stats, 0, 15 * 8)); }
     HIP_TRY_C(hipEventCreate(&e0));
     HIP_TRY_C(hipEventCreate(&e1));
     HIP_TRY_C(hipEventRecord(e0, nullptr));
@@ -516,11 +535,12 @@ int rtx_render(rtx_scene *sc, const rtx_render_params *p, uint8_t *rgb_out, int3
     HIP_TRY_C(hipMemcpy(rgb_out, d_rgb, px * 3, hipMemcpyDeviceToHost));
     if (hit_id_out) HIP_TRY_C(hipMemcpy(hit_id_out, d_hit, px * 4, hipMemcpyDeviceToHost));
     if (stats) {
-        unsigned long long c[9];
+        unsigned long long c[15];
         HIP_TRY_C(hipMemcpy(c, d_stats, sizeof c, hipMemcpyDeviceToHost));
         stats->primary_rays = c[0]; stats->reflection_rays = c[1]; stats->shadow_rays = c[2];
         stats->shadow_occluded = c[3]; stats->closest_hits = c[4]; stats->node_visits = c[5];
         stats->box_hits = c[6]; stats->leaf_visits = c[7]; stats->triangle_tests = c[8];
+        for (int i = 0; i < 3; i++) { stats->rounds[i] = c[9 + i]; stats->lane_steps[i] = c[12 + i]; }
         float ms = 0;
         HIP_TRY_C(hipEventElapsedTime(&ms, e0, e1));
         stats->kernel_ms = ms;

@@ -20,14 +20,14 @@ inline size_t render_lds_bytes(int32_t bvh_depth, uint32_t block_threads) {
 inline uint64_t render_waves(const DevRender &rp) {
     return (uint64_t)(rp.tile_w / 8) * (uint64_t)(rp.tile_h / 8) * (uint64_t)rp.owned_tiles;
 }
-// scratch a render launch needs: per lane (4 + depth) doubles and (1 + 3 * depth) ints
-inline uint64_t render_scratch_lanes(const DevRender &rp) { return (render_waves(rp) + 3) / 4 * 4 * 64; }
-inline uint64_t render_scratch_bytes(const DevRender &rp) {
-    return render_scratch_lanes(rp) * ((4 + (uint64_t)rp.depth) * 8 + (1 + 3 * (uint64_t)rp.depth) * 4);
+// scratch a render launch needs: per resident lane (4 + depth) doubles and (1 + 3 * depth) ints,
+// after one 256-byte slot for the work counter
+inline uint64_t render_scratch_bytes(uint64_t lanes, int32_t depth) {
+    return 256 + lanes * ((4 + (uint64_t)depth) * 8 + (1 + 3 * (uint64_t)depth) * 4);
 }
 
 hipError_t launch_render(const DevScene &sc, const DevRender &rp, bool prune, bool stats, uint32_t block_threads,
-                         hipStream_t st);
+                         uint32_t grid_blocks, hipStream_t st);
 hipError_t launch_divtest(uint64_t seed, uint64_t n, unsigned long long *d_mismatches, hipStream_t st);
 hipError_t launch_untile(const uint8_t *src, uint8_t *dst, int W, int H, int tile_w, int tile_h, int tiles_x, int n_ranks,
                          uint64_t rank_stride, int bpp, hipStream_t st);

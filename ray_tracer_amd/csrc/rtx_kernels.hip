@@ -227,7 +227,7 @@ __device__ __forceinline__ int clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 2
 // shadow queries (-ray, triangle, lighting sum) and the (localColor, reflectivity) pairs
 // that wait for their reflected colour (scene.hpp:122) live in a per-lane slice of a
 // global scratch buffer, written and read once per query in the SHADE step.
-enum : int { ST_INNER = 0, ST_LEAF = 1, ST_SHADE = 2, ST_DONE = 3 };
+enum : int { ST_INNER = 0, ST_LEAF = 1, ST_SHADE = 2, ST_FETCH = 3, ST_DONE = 4 };
 
 struct Lane {
     V3 o, r;             // the running query
@@ -241,7 +241,29 @@ struct Lane {
     // kind (bit 0: 1 = shadow query), reflections so far d (bits 1..3), sample s (bits 4..15),
     // light index li (bits 16..31)
     uint32_t path;
+    uint32_t pix;        // the pixel: 8x8 block number of this launch * 64 + position in the block
 };
+
+// Where pixel `pix` of this launch lies: frame coordinates and output index.
+struct PixelPos {
+    int col, row;
+    uint64_t out;
+};
+__device__ __forceinline__ PixelPos pixel_pos(uint32_t pix, const DevRender &rp) {
+    const uint32_t blocks_x = (uint32_t)rp.tile_w >> 3, per_tile = blocks_x * ((uint32_t)rp.tile_h >> 3);
+    const uint32_t blk = pix >> 6, in = pix & 63u;
+    const uint32_t local_tile = blk / per_tile, wb = blk % per_tile;
+    const uint32_t tile = (rp.tile_count > 1) ? local_tile * (uint32_t)rp.tile_count + (uint32_t)rp.tile_rank : local_tile;
+    const uint32_t tx = tile % (uint32_t)rp.tiles_x, ty = tile / (uint32_t)rp.tiles_x;
+    const uint32_t in_x = (wb % blocks_x) * 8u + (in & 7u), in_y = (wb / blocks_x) * 8u + (in >> 3);
+    PixelPos p;
+    p.col = (int)(tx * (uint32_t)rp.tile_w + in_x);
+    p.row = (int)(ty * (uint32_t)rp.tile_h + in_y);
+    p.out = (uint64_t)p.row * (uint64_t)rp.W + (uint64_t)p.col;
+    if (rp.layout == RTX_LAYOUT_PACKED_TILES_)
+        p.out = ((uint64_t)local_tile * (uint32_t)rp.tile_h + in_y) * (uint32_t)rp.tile_w + in_x;
+    return p;
+}
 __device__ __forceinline__ uint32_t path_kind(uint32_t p) { return p & 1u; }
 __device__ __forceinline__ uint32_t path_d(uint32_t p) { return (p >> 1) & 7u; }
 __device__ __forceinline__ uint32_t path_s(uint32_t p) { return (p >> 4) & 0xFFFu; }
@@ -414,7 +436,7 @@ struct PixelSum {
 // A finished query (scene.hpp:89-183).  Leaves the lane with a new query (ST_INNER) or done.
 template <bool PRUNE, bool STATS>
 __device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScene &sc, const DevRender &rp, const Scratch &scr,
-                                           int col, int row, uint64_t out, Counters &c) {
+                                           Counters &c) {
     const uint32_t n_lights = sc.n_point + sc.n_dir;
     const uint32_t kind = path_kind(L.path), s = path_s(L.path);
     uint32_t d = path_d(L.path), li = path_li(L.path);
@@ -424,8 +446,9 @@ __device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScen
     if (kind == 0) {
         // Scene::traceRay after the closest-hit query (scene.hpp:97-111)
         if (STATS) c.v[d == 0 ? C_PRIMARY : C_REFLECTION]++;
-        if (d == 0 && s == 0) {
-            const uint64_t k = (uint64_t)row * (uint64_t)rp.W + (uint64_t)col;
+        if (d == 0 && s == 0 && (rp.hit || rp.t)) {
+            const PixelPos pp = pixel_pos(L.pix, rp);
+            const uint64_t k = (uint64_t)pp.row * (uint64_t)rp.W + (uint64_t)pp.col;
             if (rp.hit) rp.hit[k] = (L.best_pos >= 0) ? (int32_t)sc.tris[L.best_pos].orig_id : -1;
             if (rp.t) rp.t[k] = L.best_t;
         }
@@ -511,6 +534,8 @@ __device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScen
         cb = (int)(lb * keep) + (int)(cb * refl);
     }
     // putPixel (src/main.cpp:90-94) + the clamp of saveCanvas (src/main.cpp:107)
+    const PixelPos pp = pixel_pos(L.pix, rp);
+    const uint64_t out = pp.out;
     if (rp.spp == 1) {
         if (rp.rgb) {
             rp.rgb[3 * out + 0] = (uint8_t)clamp255(cr);
@@ -518,12 +543,12 @@ __device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScen
             rp.rgb[3 * out + 2] = (uint8_t)clamp255(cb);
         }
         if (rp.rgb_i32) { rp.rgb_i32[3 * out + 0] = cr; rp.rgb_i32[3 * out + 1] = cg; rp.rgb_i32[3 * out + 2] = cb; }
-        L.state = ST_DONE;
+        L.state = ST_FETCH;
         return;
     }
     acc.r += clamp255(cr); acc.g += clamp255(cg); acc.b += clamp255(cb);
     if (s + 1 < (uint32_t)rp.spp) {
-        primary_ray(L, sc, rp, col, row, s + 1);
+        primary_ray(L, sc, rp, pp.col, pp.row, s + 1);
         start_query(L, sc, PRUNE);
         return;
     }
@@ -534,7 +559,7 @@ __device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScen
         rp.rgb[3 * out + 2] = (uint8_t)((acc.b + spp / 2) / spp);
     }
     if (rp.rgb_i32) { rp.rgb_i32[3 * out + 0] = acc.r; rp.rgb_i32[3 * out + 1] = acc.g; rp.rgb_i32[3 * out + 2] = acc.b; }
-    L.state = ST_DONE;
+    L.state = ST_FETCH;
 }
 
 template <bool PRUNE, bool STATS>
@@ -543,57 +568,97 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t waves_per_block = blockDim.x >> 6;
-    const uint32_t blocks_x = (uint32_t)rp.tile_w >> 3, blocks_y = (uint32_t)rp.tile_h >> 3;
-    const uint32_t per_tile = blocks_x * blocks_y;
-    const uint64_t gw = (uint64_t)blockIdx.x * waves_per_block + wave;
-    const uint32_t local_tile = (uint32_t)(gw / per_tile);
-    const uint32_t wb = (uint32_t)(gw % per_tile);
-    if (local_tile >= (uint32_t)rp.owned_tiles) return;
+    const uint64_t gw = (uint64_t)blockIdx.x * waves_per_block + wave;   // resident wave slot
     const unsigned long long wave_t0 = rp.wave_log ? wall_clock64() : 0;
-    const uint32_t tile = (rp.tile_count > 1) ? local_tile * (uint32_t)rp.tile_count + (uint32_t)rp.tile_rank : local_tile;
-    const uint32_t tx = tile % (uint32_t)rp.tiles_x, ty = tile / (uint32_t)rp.tiles_x;
-    const uint32_t in_x = (wb % blocks_x) * 8u + (lane & 7u), in_y = (wb / blocks_x) * 8u + (lane >> 3);
-    const int col = (int)(tx * (uint32_t)rp.tile_w + in_x), row = (int)(ty * (uint32_t)rp.tile_h + in_y);
-    uint64_t out = (uint64_t)row * (uint64_t)rp.W + (uint64_t)col;
-    if (rp.layout == RTX_LAYOUT_PACKED_TILES_)
-        out = ((uint64_t)local_tile * (uint32_t)rp.tile_h + in_y) * (uint32_t)rp.tile_w + in_x;
 
     const uint32_t stride = rp.stack_stride;
     uint32_t *stack = lds + threadIdx.x;
     const Scratch scr = {rp.scratch_f64, rp.scratch_i32, rp.scratch_lanes, gw * 64u + lane};
     Counters c;
     if (STATS) for (int i = 0; i < 9; i++) c.v[i] = 0;
+    // STATS: rounds the wave ran of each kind and the lanes that took part (kept by lane 0)
+    unsigned long long rounds[3] = {0, 0, 0}, lane_steps[3] = {0, 0, 0};
 
     Lane L;
     PixelSum acc = {0, 0, 0};
-    L.state = ST_DONE;
+    L.state = ST_FETCH;
     L.best_t = RTX_INF; L.best_pos = -1; L.first = 0; L.count = 0; L.sp = 0; L.slack = 0; L.lim = {0, 0, 0};
-    L.o = {0, 0, 0}; L.r = {0, 0, 1}; L.path = 0;
+    L.o = {0, 0, 0}; L.r = {0, 0, 1}; L.path = 0; L.pix = 0;
     L.rd = RayDiv{0, 0, 0, 0};
-    if (col >= rp.x0 && col < rp.x1 && row >= rp.y0 && row < rp.y1) {
-        primary_ray(L, sc, rp, col, row, 0);
-        start_query(L, sc, PRUNE);
-    }
+
+    // The launch is persistent: it has only as many waves as the chip holds, and a wave keeps
+    // drawing 8x8-pixel blocks from a global counter (`work`) until the frame's blocks run out.
+    // `cursor`/`cursor_end` (wave-uniform) are the pixels of the wave's current block not yet
+    // handed to a lane.  A lane whose pixel is finished takes the next one right away, so lanes
+    // behind cheap pixels (background, early misses) do not idle while their neighbours
+    // follow three reflections.
+    uint32_t cursor = 0, cursor_end = 0;
+    bool drained = false;          // the global counter ran past the last block
 
     for (;;) {
         const unsigned long long m_inner = __ballot(L.state == ST_INNER);
         const unsigned long long m_leaf = __ballot(L.state == ST_LEAF);
         const unsigned long long m_shade = __ballot(L.state == ST_SHADE);
-        if ((m_inner | m_leaf | m_shade) == 0) break;                   // every lane done
+        const unsigned long long m_fetch = __ballot(L.state == ST_FETCH);
+        if ((m_inner | m_leaf | m_shade | m_fetch) == 0) break;         // every lane done
         // wave-uniform choice: the kind of step most lanes wait for (weighted)
         const int w_inner = __popcll(m_inner) * rp.w_inner, w_leaf = __popcll(m_leaf) * rp.w_leaf,
-                  w_shade = __popcll(m_shade) * rp.w_shade;
+                  w_shade = __popcll(m_shade | m_fetch) * rp.w_shade;
         if (w_inner >= w_leaf && w_inner >= w_shade) {
+            if (STATS && lane == 0) { rounds[0]++; lane_steps[0] += __popcll(m_inner); }
             if (L.state == ST_INNER) inner_step<PRUNE, STATS>(L, sc, stack, stride, c);
         } else if (w_leaf >= w_shade) {
+            if (STATS && lane == 0) { rounds[1]++; lane_steps[1] += __popcll(m_leaf); }
             if (L.state == ST_LEAF) leaf_step<PRUNE, STATS>(L, sc, stack, stride, c);
         } else {
-            if (L.state == ST_SHADE) shade_step<PRUNE, STATS>(L, acc, sc, rp, scr, col, row, out, c);
+            if (STATS && lane == 0) { rounds[2]++; lane_steps[2] += __popcll(m_shade); }
+            if (L.state == ST_SHADE) shade_step<PRUNE, STATS>(L, acc, sc, rp, scr, c);
+            // hand pixels to the lanes without one, in lane order
+            unsigned long long need = __ballot(L.state == ST_FETCH);
+            while (need) {
+                if (cursor == cursor_end && !drained) {
+                    uint32_t blk = 0;
+                    if (lane == 0) blk = atomicAdd(rp.work, 1u);
+                    blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)blk);
+                    if (blk >= rp.total_blocks) drained = true;
+                    else { cursor = blk * 64u; cursor_end = cursor + 64u; }
+                }
+                if (cursor == cursor_end) {                             // nothing left anywhere
+                    if (L.state == ST_FETCH) L.state = ST_DONE;
+                    break;
+                }
+                const uint32_t avail = cursor_end - cursor;
+                const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                if (L.state == ST_FETCH && rank < avail) {
+                    L.pix = cursor + rank;
+                    const PixelPos pp = pixel_pos(L.pix, rp);
+                    // outside the frame or the window: nothing to render, the lane asks again
+                    if (pp.col >= rp.x0 && pp.col < rp.x1 && pp.row >= rp.y0 && pp.row < rp.y1) {
+                        acc = {0, 0, 0};
+                        primary_ray(L, sc, rp, pp.col, pp.row, 0);
+                        start_query(L, sc, PRUNE);
+                    }
+                }
+                const uint32_t n_need = (uint32_t)__popcll(need);
+                cursor += n_need < avail ? n_need : avail;
+                // lanes still without a pixel: those the block could not serve and those whose pixel
+                // was outside the window; go round again only if work is left for them
+                need = __ballot(L.state == ST_FETCH);
+                if (cursor == cursor_end && drained) {
+                    if (L.state == ST_FETCH) L.state = ST_DONE;
+                    break;
+                }
+            }
         }
     }
     if (STATS && rp.stats) {
         for (int i = 0; i < 9; i++)
             if (c.v[i]) atomicAdd(&rp.stats[i], c.v[i]);
+        if (lane == 0)
+            for (int i = 0; i < 3; i++) {
+                atomicAdd(&rp.stats[9 + i], rounds[i]);
+                atomicAdd(&rp.stats[12 + i], lane_steps[i]);
+            }
     }
     if (rp.wave_log && lane == 0) {
         rp.wave_log[2 * gw] = wave_t0;
@@ -643,13 +708,9 @@ __global__ void __launch_bounds__(256) untile_kernel(const uint8_t *__restrict__
 }  // namespace
 
 hipError_t launch_render(const DevScene &sc, const DevRender &rp, bool prune, bool stats, uint32_t block_threads,
-                         hipStream_t st) {
-    const uint64_t waves = render_waves(rp);
-    if (waves == 0) return hipSuccess;
-    const uint32_t wpb = block_threads / 64;
-    const uint64_t blocks = (waves + wpb - 1) / wpb;
-    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    dim3 grid((uint32_t)blocks), block(block_threads);
+                         uint32_t grid_blocks, hipStream_t st) {
+    if (rp.total_blocks == 0 || grid_blocks == 0) return hipSuccess;
+    dim3 grid(grid_blocks), block(block_threads);
     const size_t lds = render_lds_bytes(sc.bvh_depth, block_threads);
     if (prune && stats) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, lds, st, sc, rp);
     else if (prune) hipLaunchKernelGGL((render_kernel<true, false>), grid, block, lds, st, sc, rp);

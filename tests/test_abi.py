@@ -27,7 +27,7 @@ def test_struct_sizes_match_the_header():
     assert ctypes.sizeof(rt.BvhNode) == 64          # the reference's BVHNode
     assert ctypes.sizeof(rt.Light) == 32
     assert ctypes.sizeof(rt.RenderParams) == 64
-    assert ctypes.sizeof(rt.Stats) == 80
+    assert ctypes.sizeof(rt.Stats) == 128
 
 
 def test_host_only_calls_work_without_gpu():

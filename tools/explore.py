@@ -40,7 +40,11 @@ if "weights" in exps:
     for wi, wl, ws in ((1, 1, 1), (2, 1, 1), (1, 2, 2), (1, 4, 4), (4, 1, 1), (1, 2, 1), (1, 1, 2), (1, 8, 8), (2, 3, 3)):
         for ch in (64, 256):
             run(f"chunk={ch} weights inner/leaf/shade={wi}/{wl}/{ws}", {"RTX_CHUNK": ch, "RTX_W_INNER": wi, "RTX_W_LEAF": wl, "RTX_W_SHADE": ws})
+if "xcd" in exps:
+    for t in (32, 64):
+        for g in (0, 1, 2, 4, 8, 16, 32, 64, 128):
+            run(f"tile={t} xcd_group={g}", {"RTX_XCD_GROUP": g}, tile=(t, t))
+    os.environ["RTX_XCD_GROUP"] = "0"
 if "tile" in exps:
     for t in (8, 16, 32, 64):
-        for ch in (64, 256):
-            run(f"tile={t} chunk={ch}", {"RTX_CHUNK": ch, "RTX_W_INNER": 1, "RTX_W_LEAF": 1, "RTX_W_SHADE": 1}, tile=(t, t))
+        run(f"tile={t}", {}, tile=(t, t))
