@@ -454,7 +454,7 @@ int rtx_render_device(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8,
     if (total_blocks >= (1ull << 26)) return fail(RTX_ERR_UNSUPPORTED, "more than 2^32 pixels in one launch");
     r.total_blocks = (uint32_t)total_blocks;
     const uint32_t wpb = block / 64;
-    uint64_t resident = (uint64_t)sc->cu_count * (uint64_t)knob("RTX_BLOCKS_PER_CU", 5) * (256 / block);
+    uint64_t resident = (uint64_t)sc->cu_count * (uint64_t)knob("RTX_BLOCKS_PER_CU", rtx::render_blocks_per_cu()) * (256 / block);
     uint64_t grid_blocks = (total_blocks + wpb - 1) / wpb;
     if (grid_blocks > resident) grid_blocks = resident;
     // Scratch: a work counter, then (4 + depth) doubles and (1 + 3*depth) ints per resident lane.

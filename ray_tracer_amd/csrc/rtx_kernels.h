@@ -26,6 +26,8 @@ inline uint64_t render_scratch_bytes(uint64_t lanes, int32_t depth) {
     return 256 + lanes * ((4 + (uint64_t)depth) * 8 + (1 + 3 * (uint64_t)depth) * 4);
 }
 
+// 256-thread blocks of the render kernel one CU keeps resident (= its waves per SIMD)
+int render_blocks_per_cu();
 hipError_t launch_render(const DevScene &sc, const DevRender &rp, bool prune, bool stats, uint32_t block_threads,
                          uint32_t grid_blocks, hipStream_t st);
 hipError_t launch_divtest(uint64_t seed, uint64_t n, unsigned long long *d_mismatches, hipStream_t st);

@@ -25,7 +25,7 @@ namespace {
 // second __launch_bounds__ argument of the render kernel: waves per SIMD the register
 // allocator must leave room for
 #ifndef RTX_WAVES_PER_EU
-#define RTX_WAVES_PER_EU 5
+#define RTX_WAVES_PER_EU 4
 #endif
 // include/common.hpp:12: DBL_EPSILON * 2^20 = 2^-32
 #define RTX_EPS (2.3283064365386962890625e-10)
@@ -50,6 +50,13 @@ __device__ __forceinline__ double smax(double a, double b) { return (a < b) ? b 
 
 __device__ __forceinline__ V3 ld3(const double *p) { return {p[0], p[1], p[2]}; }
 
+// A node pair or a triangle is fetched with 16-byte loads issued back to back and kept
+// in registers; pin() stops the compiler from sinking some of those loads below the
+// first arithmetic (it would, to save registers, and a step would then pay two or three
+// memory round trips instead of one).
+typedef double d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pin(d2 &v) { asm volatile("" : "+v"(v)); }
+
 // ---- exact division by a per-ray constant --------------------------------------
 // The slab test divides twelve box distances per node pair by the same three ray
 // components (bvh.hpp:218-229).  hipcc expands an IEEE f64 division into
@@ -67,6 +74,8 @@ struct RayDiv {
     uint32_t flags;         // RD_ZX | RD_ZY | RD_ZZ: component == 0;  RD_OK: fast path valid for this ray
 };
 enum : uint32_t { RD_ZX = 1u, RD_ZY = 2u, RD_ZZ = 4u, RD_OK = 8u };
+// RD_OK and neither r.y nor r.z zero: the pair test may use slab_pair_nz
+__device__ __forceinline__ bool rd_nz(uint32_t flags) { return (flags & (RD_OK | RD_ZY | RD_ZZ)) == RD_OK; }
 
 __device__ __forceinline__ bool exp_safe(double v) {
     // 0, or 2^-300 <= |v| <= 2^300
@@ -142,14 +151,49 @@ __device__ __forceinline__ bool slab_fast(const double *lo, const double *hi, V3
     return tmin < RTX_INF && tmax > 0 && tmax >= tmin;
 }
 
+// The pair test for the common ray: exponents tame (RD_OK) and r.y, r.z non-zero.
+// Every y/z quotient is then finite and not NaN, so std::min/std::max and v_min_f64 /
+// v_max_f64 agree in value and the compare-select chains of slab_fast collapse.
+// A zero r.x stays exact by case analysis of bvh.hpp:218-233 with tx = a * (+-inf):
+//   lo.x < o.x < hi.x      -> {tx1,tx2} = {-inf,+inf}: the x slab constrains nothing;
+//   o.x outside            -> tmin = tmax = +-inf: rejected (tmin < inf or tmax > 0 fails);
+//   o.x on a face (a = 0)  -> NaN first operand poisons tmin, or tmin = tmax = +-inf: rejected.
+// So for r.x == 0 the box passes iff lo.x < o.x < hi.x and x is left out of tmin/tmax
+// (requires lo <= hi, part of the scene's fast_div_ok).  Slot 0 (NaN bounds) is excluded
+// by the caller.
+__device__ __forceinline__ void slab_one_nz(const double *lo, const double *hi, V3 o, V3 r, const RayDiv &d, V3 lim, bool zx,
+                                            bool *hit, bool *beyond, double *tnear) {
+    const double ax1 = lo[0] - o.x, ax2 = hi[0] - o.x;
+    const double qx1 = __builtin_fma(__builtin_fma(-r.x, ax1 * d.yx, ax1), d.yx, ax1 * d.yx);
+    const double qx2 = __builtin_fma(__builtin_fma(-r.x, ax2 * d.yx, ax2), d.yx, ax2 * d.yx);
+    const double ay1 = lo[1] - o.y, ay2 = hi[1] - o.y;
+    const double qy1 = __builtin_fma(__builtin_fma(-r.y, ay1 * d.yy, ay1), d.yy, ay1 * d.yy);
+    const double qy2 = __builtin_fma(__builtin_fma(-r.y, ay2 * d.yy, ay2), d.yy, ay2 * d.yy);
+    const double az1 = lo[2] - o.z, az2 = hi[2] - o.z;
+    const double qz1 = __builtin_fma(__builtin_fma(-r.z, az1 * d.yz, az1), d.yz, az1 * d.yz);
+    const double qz2 = __builtin_fma(__builtin_fma(-r.z, az2 * d.yz, az2), d.yz, az2 * d.yz);
+    double nx = __builtin_fmin(qx1, qx2), fx = __builtin_fmax(qx1, qx2);
+    bool x_ok = true;
+    if (zx) {
+        nx = -RTX_INF;
+        fx = RTX_INF;
+        x_ok = ax1 < 0.0 && ax2 > 0.0;
+    }
+    const double ny = __builtin_fmin(qy1, qy2), fy = __builtin_fmax(qy1, qy2);
+    const double nz = __builtin_fmin(qz1, qz2), fz = __builtin_fmax(qz1, qz2);
+    const double tmin = __builtin_fmax(__builtin_fmax(nx, ny), nz);
+    const double tmax = __builtin_fmin(__builtin_fmin(fx, fy), fz);
+    *tnear = tmin;
+    *beyond = nx > lim.x || ny > lim.y || nz > lim.z;
+    *hit = x_ok && tmax > 0 && tmax >= tmin;
+}
+
 // Triangle::intersectRay (include/triangle.hpp:32-55); d = -(n.v0) comes precomputed.
-__device__ __forceinline__ bool tri_hit(const DevTri &tr, V3 o, V3 r, double *t_out) {
-    V3 n = ld3(tr.n);
+__device__ __forceinline__ bool tri_hit(V3 v0, V3 v1, V3 v2, V3 n, double d, V3 o, V3 r, double *t_out) {
     double nd = dot(n, r);
     if (__builtin_fabs(nd) < RTX_EPS) return false;
-    double t = -(dot(n, o) + tr.d) / nd;
+    double t = -(dot(n, o) + d) / nd;
     V3 p = add(o, smul(t, r));
-    V3 v0 = ld3(tr.v0), v1 = ld3(tr.v1), v2 = ld3(tr.v2);
     *t_out = t;
     if (!(dot(n, cross(sub(v1, v0), sub(p, v0))) > RTX_EPS)) return false;
     if (!(dot(n, cross(sub(v2, v1), sub(p, v1))) > RTX_EPS)) return false;
@@ -339,16 +383,25 @@ __device__ __forceinline__ void pop_node(Lane &L, const DevNode *nodes, const ui
 template <bool PRUNE, bool STATS>
 __device__ __forceinline__ void inner_step(Lane &L, const DevScene &sc, uint32_t *stack, uint32_t stride, Counters &c) {
     const DevNode *nodes = sc.nodes;
-    const DevNode &A = nodes[L.first];
-    const DevNode &B = nodes[L.first + 1];
+    // the sibling pair is one 128-byte line: eight 16-byte loads, one round trip
+    const d2 *line = reinterpret_cast<const d2 *>(nodes + L.first);
+    d2 q0 = line[0], q1 = line[1], q2 = line[2], q3 = line[3], q4 = line[4], q5 = line[5], q6 = line[6], q7 = line[7];
+    pin(q0); pin(q1); pin(q2); pin(q3); pin(q4); pin(q5); pin(q6); pin(q7);
+    const double a_lo[3] = {q0.x, q0.y, q1.x}, a_hi[3] = {q1.y, q2.x, q2.y};
+    const double b_lo[3] = {q4.x, q4.y, q5.x}, b_hi[3] = {q5.y, q6.x, q6.y};
     double ta, tb;
     bool ha, hb, beyond_a, beyond_b;
-    if (L.rd.flags & RD_OK) {
-        ha = slab_fast(A.bmin, A.bmax, L.o, L.r, L.rd, L.lim, &ta, &beyond_a);
-        hb = slab_fast(B.bmin, B.bmax, L.o, L.r, L.rd, L.lim, &tb, &beyond_b);
+    if (rd_nz(L.rd.flags)) {
+        const bool zx = L.rd.flags & RD_ZX;
+        slab_one_nz(a_lo, a_hi, L.o, L.r, L.rd, L.lim, zx, &ha, &beyond_a, &ta);
+        slab_one_nz(b_lo, b_hi, L.o, L.r, L.rd, L.lim, zx, &hb, &beyond_b, &tb);
+        ha = ha && L.first != 0;            // slot 0 is the box no ray enters
+    } else if (L.rd.flags & RD_OK) {
+        ha = slab_fast(a_lo, a_hi, L.o, L.r, L.rd, L.lim, &ta, &beyond_a);
+        hb = slab_fast(b_lo, b_hi, L.o, L.r, L.rd, L.lim, &tb, &beyond_b);
     } else {   // ray components at the ends of the exponent range: plain divisions
-        ha = slab(A.bmin, A.bmax, L.o, L.r, L.lim, &ta, &beyond_a);
-        hb = slab(B.bmin, B.bmax, L.o, L.r, L.lim, &tb, &beyond_b);
+        ha = slab(a_lo, a_hi, L.o, L.r, L.lim, &ta, &beyond_a);
+        hb = slab(b_lo, b_hi, L.o, L.r, L.lim, &tb, &beyond_b);
     }
     if (STATS) {
         c.v[C_NODES] += L.first ? 2 : 1;      // slot 0 is not a node of the tree
@@ -358,7 +411,9 @@ __device__ __forceinline__ void inner_step(Lane &L, const DevScene &sc, uint32_t
         ha = ha && !beyond_a;
         hb = hb && !beyond_b;
     }
-    const uint32_t af = A.first, ac = A.count, bf = B.first, bc = B.count;
+    // {first, count} of each child sit in the fourth 16-byte piece of its record
+    const uint32_t af = (uint32_t)__double2loint(q3.x), ac = (uint32_t)__double2hiint(q3.x);
+    const uint32_t bf = (uint32_t)__double2loint(q7.x), bc = (uint32_t)__double2hiint(q7.x);
     if (ha && hb) {
         const bool b_first = PRUNE && (tb < ta);
         stack[L.sp * stride] = b_first ? stack_entry(L.first, af, ac) : stack_entry(L.first + 1, bf, bc);
@@ -379,17 +434,23 @@ __device__ __forceinline__ void inner_step(Lane &L, const DevScene &sc, uint32_t
 
 template <bool PRUNE, bool STATS>
 __device__ __forceinline__ void leaf_step(Lane &L, const DevScene &sc, const uint32_t *stack, uint32_t stride, Counters &c) {
-    const DevTri &tr = sc.tris[L.first];
+    // 112 of the record's 128 bytes: seven 16-byte loads, one round trip
+    const d2 *rec = reinterpret_cast<const d2 *>(sc.tris + L.first);
+    d2 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6];
+    pin(q0); pin(q1); pin(q2); pin(q3); pin(q4); pin(q5); pin(q6);
+    const V3 v0 = {q0.x, q0.y, q1.x}, v1 = {q1.y, q2.x, q2.y}, v2 = {q3.x, q3.y, q4.x}, n = {q4.y, q5.x, q5.y};
+    const double plane_d = q6.x;
+    const uint32_t leaf_first = (uint32_t)__double2hiint(q6.y);          // {orig_id, leaf_first}
     if (STATS) {
         c.v[C_TRIS]++;
-        if (L.first == tr.leaf_first) c.v[C_LEAVES]++;
+        if (L.first == leaf_first) c.v[C_LEAVES]++;
     }
     double t;
-    if (tri_hit(tr, L.o, L.r, &t) && t > query_tmin(L.path) && t < query_tmax(L.path, sc.n_point)) {
+    if (tri_hit(v0, v1, v2, n, plane_d, L.o, L.r, &t) && t > query_tmin(L.path) && t < query_tmax(L.path, sc.n_point)) {
         // equal t: the later leaf wins; inside one leaf the earlier triangle stays (strict <,
         // bvh.hpp:186).  The best hit's leaf is read back only on an exact tie.
         bool better = t < L.best_t;
-        if (t == L.best_t) better = tr.leaf_first > sc.tris[L.best_pos].leaf_first;
+        if (t == L.best_t) better = leaf_first > sc.tris[L.best_pos].leaf_first;
         if (better) {
             L.best_t = t;
             L.best_pos = (int32_t)L.first;
@@ -706,6 +767,8 @@ __global__ void __launch_bounds__(256) untile_kernel(const uint8_t *__restrict__
 }
 
 }  // namespace
+
+int render_blocks_per_cu() { return RTX_WAVES_PER_EU; }
 
 hipError_t launch_render(const DevScene &sc, const DevRender &rp, bool prune, bool stats, uint32_t block_threads,
                          uint32_t grid_blocks, hipStream_t st) {

@@ -40,6 +40,14 @@ if "weights" in exps:
     for wi, wl, ws in ((1, 1, 1), (2, 1, 1), (1, 2, 2), (1, 4, 4), (4, 1, 1), (1, 2, 1), (1, 1, 2), (1, 8, 8), (2, 3, 3)):
         for ch in (64, 256):
             run(f"chunk={ch} weights inner/leaf/shade={wi}/{wl}/{ws}", {"RTX_CHUNK": ch, "RTX_W_INNER": wi, "RTX_W_LEAF": wl, "RTX_W_SHADE": ws})
+if "weights2" in exps:
+    for wi, wl, ws in ((1, 1, 1), (1, 2, 2), (2, 3, 3), (1, 3, 3), (1, 2, 4), (1, 3, 2), (2, 3, 4), (3, 4, 4), (1, 4, 4), (1, 2, 3)):
+        run(f"weights inner/leaf/shade={wi}/{wl}/{ws}", {"RTX_W_INNER": wi, "RTX_W_LEAF": wl, "RTX_W_SHADE": ws})
+    os.environ.update(RTX_W_INNER="1", RTX_W_LEAF="2", RTX_W_SHADE="2")
+if "bpc" in exps:
+    for b in (2, 3, 4, 5, 6, 8):
+        run(f"blocks per CU={b}", {"RTX_BLOCKS_PER_CU": b})
+    os.environ["RTX_BLOCKS_PER_CU"] = "5"
 if "xcd" in exps:
     for t in (32, 64):
         for g in (0, 1, 2, 4, 8, 16, 32, 64, 128):

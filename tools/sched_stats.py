@@ -17,3 +17,13 @@ print(st.scheduling())
 rays = d["rays"]
 tot_rounds = sum(st.rounds)
 print(f"rays {rays}  nodes/ray {d['node_visits']/rays:.1f}  tris/ray {d['triangle_tests']/rays:.2f}  wave-rounds {tot_rounds}  wave-rounds per 64 rays {tot_rounds*64/rays:.1f}  lane-steps/ray {sum(st.lane_steps)/rays:.1f}")
+import torch
+buf = torch.zeros(W * H * 3, dtype=torch.uint8, device="cuda")
+p = rt.make_params(W, H, traversal=mode)
+ts = []
+for _ in range(4):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); dev.render_device(p, rgb_u8=buf.data_ptr(), stream=torch.cuda.current_stream().cuda_stream); b.record(); torch.cuda.synchronize()
+    ts.append(a.elapsed_time(b))
+ms = min(ts[1:])
+print(f"kernel {ms:.3f} ms  {rays/ms/1e3:.0f} Mrays/s  ns per wave-round (1024 SIMDs busy) {ms*1e6*1024/tot_rounds:.0f}  scene MB {dev.device_bytes/1e6:.0f}")
