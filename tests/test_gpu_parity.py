@@ -186,3 +186,65 @@ def test_fast_division_is_bit_exact():
     # 2^28 operand pairs per seed, compared bitwise with the compiler's IEEE division on the device
     for seed in (1, 2):
         assert rt.selftest_division(1 << 28, seed) == 0
+
+
+def _axis_scene(scale=1.0):
+    """Camera looking straight down +z (no rotation): the centre column has r.x == 0 and the
+    centre row r.y == 0 exactly; lights along the axes give shadow rays with two zero components;
+    wall triangles lie in axis planes so ray origins sit exactly on box faces."""
+    rng = np.random.default_rng(99)
+    n = 120
+    centers = rng.uniform(-3, 3, size=(n, 1, 3)) + np.array([0, 0, 8.0])
+    verts = centers + rng.uniform(-1.0, 1.0, size=(n, 3, 3))
+    walls = np.array([[[-5, -5, 12], [5, -5, 12], [5, 5, 12]], [[5, 5, 12], [-5, 5, 12], [-5, -5, 12]],     # z = 12
+                      [[-5, -5, 2], [-5, -5, 12], [-5, 5, 12]], [[-5, 5, 12], [-5, 5, 2], [-5, -5, 2]],       # x = -5
+                      [[-5, -5, 2], [5, -5, 2], [5, -5, 12]], [[5, -5, 12], [-5, -5, 12], [-5, -5, 2]]], float)  # y = -5
+    verts[:6] = walls
+    verts = verts * scale
+    colors = rng.integers(30, 256, size=(n, 3)).astype(np.int32)
+    spec = np.ones(n, np.int32)
+    refl = rng.choice(np.array([-1.0, 0.3, 0.5]), size=n)
+    kw = dict(camera_position=(0.0, 0.0, 0.0), camera_rotation_deg=(0.0, 0.0, 0.0), viewport=(1.0, 1.0, 1.0),
+              background=(10, 20, 30), ambient=0.1,
+              point_lights=[(0.5, (0.0, 0.0, 1.0 * scale))],
+              directional_lights=[(0.3, (0.0, 1.0, 0.0)), (0.3, (1.0, 0.0, 0.0)), (0.2, (0.0, 0.0, -1.0)), (0.2, (0.0, 1.0, -1.0))])
+    return verts.reshape(n, 9), colors, spec, refl, kw
+
+
+@pytest.mark.parametrize("mode", [rt.TRAVERSAL_REFERENCE, rt.TRAVERSAL_PRUNED])
+def test_axis_aligned_rays_zero_components(mode):
+    v, col, spec, refl, cam = _axis_scene()
+    dev = rt.Scene(rt.HostScene.from_arrays(v, col, spec, refl, **cam))
+    ora = OracleScene.from_arrays(v, col, spec, refl, **cam)
+    want = ora.render(130, 98, depth=3)
+    got = dev.render(130, 98, depth=3, traversal=mode, want_stats=True)
+    assert np.array_equal(got.hit, want["hit"])
+    assert np.array_equal(got.rgb, want["rgb_u8"])
+    if mode == rt.TRAVERSAL_REFERENCE:
+        st = got.stats.as_dict()
+        st.pop("kernel_ms")
+        assert st == want["census"].as_dict()
+    dev.close()
+
+
+@pytest.mark.parametrize("mode", [rt.TRAVERSAL_REFERENCE, rt.TRAVERSAL_PRUNED])
+def test_extreme_ray_components_take_the_plain_division_path(mode):
+    # a point light 2^310 away and a light direction with a 1e-200 component give shadow rays whose
+    # components lie outside 2^-300..2^300: those rays must leave the reciprocal shortcut
+    v, col, spec, refl, cam = _axis_scene()
+    cam["camera_rotation_deg"] = (1.0, 2.0, 3.0)
+    cam["point_lights"] = [(0.5, (2.0 ** 310, 2.0 ** 311, -(2.0 ** 310)))]
+    cam["directional_lights"] = [(0.4, (1e-200, 1.0, -1.0)), (0.2, (1.0, 1e300, 0.5))]
+    dev = rt.Scene(rt.HostScene.from_arrays(v, col, spec, refl, **cam))
+    ora = OracleScene.from_arrays(v, col, spec, refl, **cam)
+    want = ora.render(96, 64, depth=2)
+    got = dev.render(96, 64, depth=2, traversal=mode, want_stats=True)
+    assert (want["hit"] >= 0).any() and want["census"].shadow_occluded > 0
+    assert want["census"].shadow_occluded < want["census"].shadow_rays
+    assert np.array_equal(got.hit, want["hit"])
+    assert np.array_equal(got.rgb, want["rgb_u8"])
+    if mode == rt.TRAVERSAL_REFERENCE:
+        st = got.stats.as_dict()
+        st.pop("kernel_ms")
+        assert st == want["census"].as_dict()
+    dev.close()
