@@ -22,6 +22,17 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
 
 
+def profiled_traffic(workload_key):
+    """HBM bytes per launch of the render kernel from the committed PMC passes (profiles/traffic.json,
+    written by tools/pmc_summary.py): FETCH_SIZE is doubled as the gfx950 note on that counter
+    prescribes, WRITE_SIZE taken as is; both are reported in KiB by rocprofv3."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[workload_key]
+        return {"bytes": int((2 * t["FETCH_SIZE_KiB"] + t["WRITE_SIZE_KiB"]) * 1024), "source": t["source"]}
+    except Exception:
+        return None
+
+
 def cpu_baseline(scene_name, n_tris, W, H, depth, obj_path):
     """Times the CPU path on the host cores: oracle/_ref/ref_bvh (the reference's own headers,
     compiled in the build container) when present, else the oracle restatement."""
@@ -186,6 +197,7 @@ def main():
     mrays = rays / (ms_per_step * 1e-3) / 1e6
     launch_alg_bytes = alg_bytes_frame / world         # this rank's launch covers 1/world of the tiles
     achieved = launch_alg_bytes / (kernel_ms * 1e-3) / 1e9
+    traffic = profiled_traffic(f"{args.scene}_{W}x{H}_{args.mode}") if world == 1 and not args.obj else None
     result = {
         "metric": "Mrays/s (primary+reflection+shadow)",
         "value": round(mrays, 2),
@@ -217,7 +229,8 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None,
+            "traffic": traffic["bytes"] if traffic else None,
+            "traffic_source": traffic["source"] if traffic else None,
             "kernel": "render_kernel",
             "kernel_ms": round(kernel_ms, 4),
             "algorithmic_bytes_per_ray": round(bytes_per_ray, 1),

@@ -89,7 +89,12 @@ struct DevRender {
     double *scratch_f64;
     int32_t *scratch_i32;
     uint64_t scratch_lanes;
-    uint32_t *work;            // next 8x8 block to hand out (zeroed before every launch)
+    // work queues: queue q owns the local tiles tile_order[9 + tile_order[q] .. 9 + tile_order[q+1]);
+    // work[32*q] counts the 8x8 blocks handed out from it (zeroed before every launch)
+    uint32_t *work;
+    const uint32_t *tile_order;
+    uint32_t n_queues;
+    uint32_t fetch_blocks;     // 8x8 blocks a wave takes from a queue at a time (divides the blocks per tile)
     uint32_t total_blocks;     // 8x8 blocks of this launch
     int32_t w_inner, w_leaf, w_shade;   // weights of the wave's step choice
     uint32_t xcd_group;                 // blocks per XCD-local run (0 = plain block order)

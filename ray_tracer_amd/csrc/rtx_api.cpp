@@ -2,6 +2,7 @@
 // render launches, tile re-assembly and PPM output.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -31,6 +32,10 @@ struct rtx_scene {
     // per-lane scratch of the render kernel, kept between frames and grown on demand
     void *d_scratch = nullptr;
     uint64_t scratch_bytes = 0;
+    // work-queue layout of the last launch geometry (see build_tile_order)
+    void *d_order = nullptr;
+    uint64_t order_capacity = 0;
+    std::vector<int64_t> order_key;
     uint64_t bytes = 0;
     uint64_t n_triangles = 0;
     int cu_count = 256;
@@ -390,6 +395,7 @@ void rtx_scene_destroy(rtx_scene *sc) {
     (void)hipFree(sc->d_mats);
     (void)hipFree(sc->d_lights);
     (void)hipFree(sc->d_scratch);
+    (void)hipFree(sc->d_order);
     delete sc;
 }
 
@@ -471,9 +477,58 @@ int rtx_render_device(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8,
         }
         r.work = (uint32_t *)sc->d_scratch;
         r.scratch_lanes = lanes;
-        r.scratch_f64 = (double *)((char *)sc->d_scratch + 256);
+        r.scratch_f64 = (double *)((char *)sc->d_scratch + 1024);
         r.scratch_i32 = (int32_t *)((char *)r.scratch_f64 + lanes * (4 + (uint64_t)r.depth) * 8);
-        HIP_TRY(hipMemsetAsync(r.work, 0, 256, (hipStream_t)stream));
+        HIP_TRY(hipMemsetAsync(r.work, 0, 1024, (hipStream_t)stream));
+    }
+    // Work queues.  The frame's tiles are grouped into macro tiles (RTX_MACRO x RTX_MACRO tiles of
+    // screen neighbours) and the macro tiles dealt to 8 queues, one per XCD; a wave serves its own
+    // XCD's queue first.  The layout depends only on the launch geometry and is kept on the device
+    // until that changes.
+    {
+        const int n_queues = knob("RTX_XCD_QUEUES", 1) ? 8 : 1;
+        const int macro = std::max(1, knob("RTX_MACRO", 8));
+        const std::vector<int64_t> key = {r.W, r.H, r.tile_w, r.tile_h, r.tile_rank, r.tile_count, n_queues, macro};
+        if (key != sc->order_key) {
+            const uint32_t owned = (uint32_t)r.owned_tiles;
+            std::vector<std::vector<uint32_t>> per_queue(n_queues);
+            const int macros_x = (r.tiles_x + macro - 1) / macro;
+            // macro tiles in row-major order, dealt round-robin with a skew per macro row
+            std::vector<std::vector<uint32_t>> per_macro((size_t)macros_x * ((r.tiles_y + macro - 1) / macro));
+            for (uint32_t lt = 0; lt < owned; lt++) {
+                const uint32_t tile = r.tile_count > 1 ? lt * (uint32_t)r.tile_count + (uint32_t)r.tile_rank : lt;
+                const int tx = (int)(tile % (uint32_t)r.tiles_x), ty = (int)(tile / (uint32_t)r.tiles_x);
+                per_macro[(size_t)(ty / macro) * macros_x + tx / macro].push_back(lt);
+            }
+            for (size_t m = 0; m < per_macro.size(); m++) {
+                const int mx = (int)(m % macros_x), my = (int)(m / macros_x);
+                auto &q = per_queue[(mx + 3 * my) % n_queues];
+                q.insert(q.end(), per_macro[m].begin(), per_macro[m].end());
+            }
+            std::vector<uint32_t> order(9, 0);
+            for (int q = 0; q < 8; q++) {
+                if (q < n_queues) order.insert(order.end(), per_queue[q].begin(), per_queue[q].end());
+                order[q + 1] = (uint32_t)(order.size() - 9);
+            }
+            const uint64_t bytes = order.size() * 4;
+            if (bytes > sc->order_capacity) {
+                if (sc->d_order) HIP_TRY(hipFree(sc->d_order));
+                sc->d_order = nullptr;
+                sc->order_capacity = 0;
+                HIP_TRY(hipMalloc(&sc->d_order, bytes));
+                sc->order_capacity = bytes;
+            }
+            // earlier launches may still be reading the previous layout
+            HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+            HIP_TRY(hipMemcpy(sc->d_order, order.data(), bytes, hipMemcpyHostToDevice));
+            sc->order_key = key;
+        }
+        r.tile_order = (const uint32_t *)sc->d_order;
+        r.n_queues = (uint32_t)n_queues;
+        const uint32_t per_tile = (uint32_t)(r.tile_w / 8) * (uint32_t)(r.tile_h / 8);
+        uint32_t fb = (uint32_t)std::max(1, knob("RTX_FETCH_BLOCKS", 1));
+        while (per_tile % fb) fb--;
+        r.fetch_blocks = fb;
     }
     // Diagnostics: RTX_WAVE_LOG=<file> records every wave's start/end tick (100 MHz) of this
     // launch and writes them as raw u64 pairs.  Synchronous; never set in production.

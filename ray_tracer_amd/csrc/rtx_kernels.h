@@ -21,9 +21,9 @@ inline uint64_t render_waves(const DevRender &rp) {
     return (uint64_t)(rp.tile_w / 8) * (uint64_t)(rp.tile_h / 8) * (uint64_t)rp.owned_tiles;
 }
 // scratch a render launch needs: per resident lane (4 + depth) doubles and (1 + 3 * depth) ints,
-// after one 256-byte slot for the work counter
+// after 1 KiB for the work counters
 inline uint64_t render_scratch_bytes(uint64_t lanes, int32_t depth) {
-    return 256 + lanes * ((4 + (uint64_t)depth) * 8 + (1 + 3 * (uint64_t)depth) * 4);
+    return 1024 + lanes * ((4 + (uint64_t)depth) * 8 + (1 + 3 * (uint64_t)depth) * 4);
 }
 
 // 256-thread blocks of the render kernel one CU keeps resident (= its waves per SIMD)

@@ -648,13 +648,17 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
     L.rd = RayDiv{0, 0, 0, 0};
 
     // The launch is persistent: it has only as many waves as the chip holds, and a wave keeps
-    // drawing 8x8-pixel blocks from a global counter (`work`) until the frame's blocks run out.
+    // drawing 8x8-pixel blocks from global work queues (`work`, `tile_order`) until they run dry.
     // `cursor`/`cursor_end` (wave-uniform) are the pixels of the wave's current block not yet
     // handed to a lane.  A lane whose pixel is finished takes the next one right away, so lanes
     // behind cheap pixels (background, early misses) do not idle while their neighbours
     // follow three reflections.
     uint32_t cursor = 0, cursor_end = 0;
-    bool drained = false;          // the global counter ran past the last block
+    bool drained = false;          // every queue ran past its last block
+    uint32_t exhausted = 0;        // queues this wave has seen empty
+    const uint32_t per_tile = ((uint32_t)rp.tile_w >> 3) * ((uint32_t)rp.tile_h >> 3);
+    // HW_REG_XCC_ID (id 20), bits 3:0: the XCD this wave runs on
+    const uint32_t home_queue = rp.n_queues > 1 ? ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % rp.n_queues : 0u;
 
     for (;;) {
         const unsigned long long m_inner = __ballot(L.state == ST_INNER);
@@ -678,11 +682,23 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
             unsigned long long need = __ballot(L.state == ST_FETCH);
             while (need) {
                 if (cursor == cursor_end && !drained) {
-                    uint32_t blk = 0;
-                    if (lane == 0) blk = atomicAdd(rp.work, 1u);
-                    blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)blk);
-                    if (blk >= rp.total_blocks) drained = true;
-                    else { cursor = blk * 64u; cursor_end = cursor + 64u; }
+                    // Next 8x8 block: from the queue of this wave's XCD first (its tiles are
+                    // screen neighbours, so the XCD's L2 keeps seeing the same part of the BVH),
+                    // then from the other queues.  Which queue served a block only affects speed.
+                    uint32_t got = 0xFFFFFFFFu;
+                    for (uint32_t k = 0; k < rp.n_queues && got == 0xFFFFFFFFu; k++) {
+                        const uint32_t q = (home_queue + k) % rp.n_queues;
+                        if (exhausted & (1u << q)) continue;
+                        const uint32_t q_begin = rp.tile_order[q], q_tiles = rp.tile_order[q + 1] - q_begin;
+                        uint32_t i = 0;
+                        if (lane == 0) i = atomicAdd(rp.work + q * 32u, rp.fetch_blocks);
+                        i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+                        // fetch_blocks divides per_tile: a fetch never straddles two tiles
+                        if (i < q_tiles * per_tile) got = rp.tile_order[9u + q_begin + i / per_tile] * per_tile + i % per_tile;
+                        else exhausted |= 1u << q;
+                    }
+                    if (got == 0xFFFFFFFFu) drained = true;
+                    else { cursor = got * 64u; cursor_end = cursor + 64u * rp.fetch_blocks; }
                 }
                 if (cursor == cursor_end) {                             // nothing left anywhere
                     if (L.state == ST_FETCH) L.state = ST_DONE;

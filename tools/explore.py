@@ -48,6 +48,16 @@ if "bpc" in exps:
     for b in (2, 3, 4, 5, 6, 8):
         run(f"blocks per CU={b}", {"RTX_BLOCKS_PER_CU": b})
     os.environ["RTX_BLOCKS_PER_CU"] = "5"
+if "queues" in exps:
+    run("single queue", {"RTX_XCD_QUEUES": 0})
+    for m in (1, 2, 4, 8, 16, 32):
+        run(f"8 XCD queues, macro={m} tiles", {"RTX_XCD_QUEUES": 1, "RTX_MACRO": m})
+    run("single queue", {"RTX_XCD_QUEUES": 0})
+    os.environ.update(RTX_XCD_QUEUES="1", RTX_MACRO="8")
+if "fetch" in exps:
+    for f in (1, 2, 4, 8, 16):
+        run(f"fetch_blocks={f}", {"RTX_FETCH_BLOCKS": f})
+    os.environ["RTX_FETCH_BLOCKS"] = "1"
 if "xcd" in exps:
     for t in (32, 64):
         for g in (0, 1, 2, 4, 8, 16, 32, 64, 128):

@@ -19,3 +19,11 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recur
         if "render_kernel" in row["Name"]:
             out["kernel_trace"] = {"name": row["Name"], "calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"])}
 json.dump(out, sys.stdout if len(sys.argv) < 3 else open(sys.argv[2], "w"), indent=1, sort_keys=True)
+# optional: tools/pmc_summary.py <dir> <out.json> <traffic.json> <workload key>  -> merges the HBM traffic of
+# this profile into the table bench.py reads
+if len(sys.argv) >= 5 and "FETCH_SIZE" in out and "WRITE_SIZE" in out:
+    path, key = sys.argv[3], sys.argv[4]
+    table = json.load(open(path)) if os.path.exists(path) else {}
+    table[key] = {"FETCH_SIZE_KiB": out["FETCH_SIZE"]["mean_per_dispatch"], "WRITE_SIZE_KiB": out["WRITE_SIZE"]["mean_per_dispatch"],
+                  "source": os.path.basename(sys.argv[2])}
+    json.dump(table, open(path, "w"), indent=1, sort_keys=True)
