@@ -94,7 +94,6 @@ struct DevRender {
     uint32_t *work;
     const uint32_t *tile_order;
     uint32_t n_queues;
-    uint32_t fetch_blocks;     // 8x8 blocks a wave takes from a queue at a time (divides the blocks per tile)
     uint32_t total_blocks;     // 8x8 blocks of this launch
     int32_t w_inner, w_leaf, w_shade;   // weights of the wave's step choice
     uint32_t xcd_group;                 // blocks per XCD-local run (0 = plain block order)

@@ -90,7 +90,8 @@ struct ResolvedParams {
 int resolve_params(const rtx_render_params *p, ResolvedParams *out) {
     if (!p) return fail(RTX_ERR_INVALID, "render params are NULL");
     if (p->width < 0 || p->height < 0) return fail(RTX_ERR_INVALID, "negative canvas size");
-    if ((int64_t)p->width * p->height > (int64_t)1 << 31) return fail(RTX_ERR_UNSUPPORTED, "canvas larger than 2^31 pixels");
+    // the kernel keeps a pixel's column and row in 16 bits each
+    if (p->width > 65535 || p->height > 65535) return fail(RTX_ERR_UNSUPPORTED, "canvas larger than 65535 pixels in one dimension");
     if (p->depth < 0 || p->depth > 7) return fail(RTX_ERR_INVALID, "depth must be 0..7");
     if (p->spp < 1 || p->spp > 4096) return fail(RTX_ERR_INVALID, "spp must be 1..4096");
     if (p->traversal != RTX_TRAVERSAL_REFERENCE && p->traversal != RTX_TRAVERSAL_PRUNED) return fail(RTX_ERR_INVALID, "unknown traversal mode");
@@ -525,10 +526,7 @@ int rtx_render_device(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8,
         }
         r.tile_order = (const uint32_t *)sc->d_order;
         r.n_queues = (uint32_t)n_queues;
-        const uint32_t per_tile = (uint32_t)(r.tile_w / 8) * (uint32_t)(r.tile_h / 8);
-        uint32_t fb = (uint32_t)std::max(1, knob("RTX_FETCH_BLOCKS", 1));
-        while (per_tile % fb) fb--;
-        r.fetch_blocks = fb;
+
     }
     // Diagnostics: RTX_WAVE_LOG=<file> records every wave's start/end tick (100 MHz) of this
     // launch and writes them as raw u64 pairs.  Synchronous; never set in production.

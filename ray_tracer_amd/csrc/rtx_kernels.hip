@@ -285,29 +285,10 @@ struct Lane {
     // kind (bit 0: 1 = shadow query), reflections so far d (bits 1..3), sample s (bits 4..15),
     // light index li (bits 16..31)
     uint32_t path;
-    uint32_t pix;        // the pixel: 8x8 block number of this launch * 64 + position in the block
+    uint32_t pix;        // the pixel: column | row << 16
+    uint32_t out;        // its index in the output buffers (row-major or packed-tile layout)
 };
 
-// Where pixel `pix` of this launch lies: frame coordinates and output index.
-struct PixelPos {
-    int col, row;
-    uint64_t out;
-};
-__device__ __forceinline__ PixelPos pixel_pos(uint32_t pix, const DevRender &rp) {
-    const uint32_t blocks_x = (uint32_t)rp.tile_w >> 3, per_tile = blocks_x * ((uint32_t)rp.tile_h >> 3);
-    const uint32_t blk = pix >> 6, in = pix & 63u;
-    const uint32_t local_tile = blk / per_tile, wb = blk % per_tile;
-    const uint32_t tile = (rp.tile_count > 1) ? local_tile * (uint32_t)rp.tile_count + (uint32_t)rp.tile_rank : local_tile;
-    const uint32_t tx = tile % (uint32_t)rp.tiles_x, ty = tile / (uint32_t)rp.tiles_x;
-    const uint32_t in_x = (wb % blocks_x) * 8u + (in & 7u), in_y = (wb / blocks_x) * 8u + (in >> 3);
-    PixelPos p;
-    p.col = (int)(tx * (uint32_t)rp.tile_w + in_x);
-    p.row = (int)(ty * (uint32_t)rp.tile_h + in_y);
-    p.out = (uint64_t)p.row * (uint64_t)rp.W + (uint64_t)p.col;
-    if (rp.layout == RTX_LAYOUT_PACKED_TILES_)
-        p.out = ((uint64_t)local_tile * (uint32_t)rp.tile_h + in_y) * (uint32_t)rp.tile_w + in_x;
-    return p;
-}
 __device__ __forceinline__ uint32_t path_kind(uint32_t p) { return p & 1u; }
 __device__ __forceinline__ uint32_t path_d(uint32_t p) { return (p >> 1) & 7u; }
 __device__ __forceinline__ uint32_t path_s(uint32_t p) { return (p >> 4) & 0xFFFu; }
@@ -508,8 +489,7 @@ __device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScen
         // Scene::traceRay after the closest-hit query (scene.hpp:97-111)
         if (STATS) c.v[d == 0 ? C_PRIMARY : C_REFLECTION]++;
         if (d == 0 && s == 0 && (rp.hit || rp.t)) {
-            const PixelPos pp = pixel_pos(L.pix, rp);
-            const uint64_t k = (uint64_t)pp.row * (uint64_t)rp.W + (uint64_t)pp.col;
+            const uint64_t k = (uint64_t)(L.pix >> 16) * (uint64_t)rp.W + (uint64_t)(L.pix & 0xFFFFu);
             if (rp.hit) rp.hit[k] = (L.best_pos >= 0) ? (int32_t)sc.tris[L.best_pos].orig_id : -1;
             if (rp.t) rp.t[k] = L.best_t;
         }
@@ -595,8 +575,7 @@ __device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScen
         cb = (int)(lb * keep) + (int)(cb * refl);
     }
     // putPixel (src/main.cpp:90-94) + the clamp of saveCanvas (src/main.cpp:107)
-    const PixelPos pp = pixel_pos(L.pix, rp);
-    const uint64_t out = pp.out;
+    const uint64_t out = L.out;
     if (rp.spp == 1) {
         if (rp.rgb) {
             rp.rgb[3 * out + 0] = (uint8_t)clamp255(cr);
@@ -609,7 +588,7 @@ __device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScen
     }
     acc.r += clamp255(cr); acc.g += clamp255(cg); acc.b += clamp255(cb);
     if (s + 1 < (uint32_t)rp.spp) {
-        primary_ray(L, sc, rp, pp.col, pp.row, s + 1);
+        primary_ray(L, sc, rp, (int)(L.pix & 0xFFFFu), (int)(L.pix >> 16), s + 1);
         start_query(L, sc, PRUNE);
         return;
     }
@@ -644,7 +623,7 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
     PixelSum acc = {0, 0, 0};
     L.state = ST_FETCH;
     L.best_t = RTX_INF; L.best_pos = -1; L.first = 0; L.count = 0; L.sp = 0; L.slack = 0; L.lim = {0, 0, 0};
-    L.o = {0, 0, 0}; L.r = {0, 0, 1}; L.path = 0; L.pix = 0;
+    L.o = {0, 0, 0}; L.r = {0, 0, 1}; L.path = 0; L.pix = 0; L.out = 0;
     L.rd = RayDiv{0, 0, 0, 0};
 
     // The launch is persistent: it has only as many waves as the chip holds, and a wave keeps
@@ -653,10 +632,13 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
     // handed to a lane.  A lane whose pixel is finished takes the next one right away, so lanes
     // behind cheap pixels (background, early misses) do not idle while their neighbours
     // follow three reflections.
-    uint32_t cursor = 0, cursor_end = 0;
+    // wave-uniform: the 8x8 block being handed out (pixels cursor..63 are still free), where its
+    // top-left pixel lies in the frame and in the packed-tile output
+    uint32_t cursor = 64, block_x0 = 0, block_y0 = 0, block_packed0 = 0;
     bool drained = false;          // every queue ran past its last block
     uint32_t exhausted = 0;        // queues this wave has seen empty
-    const uint32_t per_tile = ((uint32_t)rp.tile_w >> 3) * ((uint32_t)rp.tile_h >> 3);
+    const uint32_t blocks_x = (uint32_t)rp.tile_w >> 3;
+    const uint32_t per_tile = blocks_x * ((uint32_t)rp.tile_h >> 3);
     // HW_REG_XCC_ID (id 20), bits 3:0: the XCD this wave runs on
     const uint32_t home_queue = rp.n_queues > 1 ? ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % rp.n_queues : 0u;
 
@@ -681,50 +663,54 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
             // hand pixels to the lanes without one, in lane order
             unsigned long long need = __ballot(L.state == ST_FETCH);
             while (need) {
-                if (cursor == cursor_end && !drained) {
+                if (cursor == 64u && !drained) {
                     // Next 8x8 block: from the queue of this wave's XCD first (its tiles are
                     // screen neighbours, so the XCD's L2 keeps seeing the same part of the BVH),
                     // then from the other queues.  Which queue served a block only affects speed.
-                    uint32_t got = 0xFFFFFFFFu;
-                    for (uint32_t k = 0; k < rp.n_queues && got == 0xFFFFFFFFu; k++) {
+                    drained = true;
+                    for (uint32_t k = 0; k < rp.n_queues && drained; k++) {
                         const uint32_t q = (home_queue + k) % rp.n_queues;
                         if (exhausted & (1u << q)) continue;
                         const uint32_t q_begin = rp.tile_order[q], q_tiles = rp.tile_order[q + 1] - q_begin;
                         uint32_t i = 0;
-                        if (lane == 0) i = atomicAdd(rp.work + q * 32u, rp.fetch_blocks);
+                        if (lane == 0) i = atomicAdd(rp.work + q * 32u, 1u);
                         i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
-                        // fetch_blocks divides per_tile: a fetch never straddles two tiles
-                        if (i < q_tiles * per_tile) got = rp.tile_order[9u + q_begin + i / per_tile] * per_tile + i % per_tile;
-                        else exhausted |= 1u << q;
+                        if (i >= q_tiles * per_tile) { exhausted |= 1u << q; continue; }
+                        // all wave-uniform: local tile, block inside it, frame position
+                        const uint32_t local_tile = rp.tile_order[9u + q_begin + i / per_tile], wb = i % per_tile;
+                        const uint32_t tile = (rp.tile_count > 1) ? local_tile * (uint32_t)rp.tile_count + (uint32_t)rp.tile_rank : local_tile;
+                        const uint32_t bx = (wb % blocks_x) * 8u, by = (wb / blocks_x) * 8u;
+                        block_x0 = (tile % (uint32_t)rp.tiles_x) * (uint32_t)rp.tile_w + bx;
+                        block_y0 = (tile / (uint32_t)rp.tiles_x) * (uint32_t)rp.tile_h + by;
+                        block_packed0 = (local_tile * (uint32_t)rp.tile_h + by) * (uint32_t)rp.tile_w + bx;
+                        cursor = 0;
+                        drained = false;
                     }
-                    if (got == 0xFFFFFFFFu) drained = true;
-                    else { cursor = got * 64u; cursor_end = cursor + 64u * rp.fetch_blocks; }
                 }
-                if (cursor == cursor_end) {                             // nothing left anywhere
+                if (cursor == 64u) {                                    // nothing left anywhere
                     if (L.state == ST_FETCH) L.state = ST_DONE;
                     break;
                 }
-                const uint32_t avail = cursor_end - cursor;
+                const uint32_t avail = 64u - cursor;
                 const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
                 if (L.state == ST_FETCH && rank < avail) {
-                    L.pix = cursor + rank;
-                    const PixelPos pp = pixel_pos(L.pix, rp);
+                    const uint32_t in = cursor + rank, ix = in & 7u, iy = in >> 3;
+                    const uint32_t col = block_x0 + ix, row = block_y0 + iy;
                     // outside the frame or the window: nothing to render, the lane asks again
-                    if (pp.col >= rp.x0 && pp.col < rp.x1 && pp.row >= rp.y0 && pp.row < rp.y1) {
+                    if ((int)col >= rp.x0 && (int)col < rp.x1 && (int)row >= rp.y0 && (int)row < rp.y1) {
+                        L.pix = col | (row << 16);
+                        L.out = (rp.layout == RTX_LAYOUT_PACKED_TILES_) ? block_packed0 + iy * (uint32_t)rp.tile_w + ix
+                                                                        : row * (uint32_t)rp.W + col;
                         acc = {0, 0, 0};
-                        primary_ray(L, sc, rp, pp.col, pp.row, 0);
+                        primary_ray(L, sc, rp, (int)col, (int)row, 0);
                         start_query(L, sc, PRUNE);
                     }
                 }
                 const uint32_t n_need = (uint32_t)__popcll(need);
                 cursor += n_need < avail ? n_need : avail;
                 // lanes still without a pixel: those the block could not serve and those whose pixel
-                // was outside the window; go round again only if work is left for them
+                // was outside the window
                 need = __ballot(L.state == ST_FETCH);
-                if (cursor == cursor_end && drained) {
-                    if (L.state == ST_FETCH) L.state = ST_DONE;
-                    break;
-                }
             }
         }
     }
