@@ -68,6 +68,10 @@ def main():
     ap.add_argument("--tile", type=int, default=32)
     ap.add_argument("--obj", default=None, help="real .obj for the scene (default: the seeded stand-in mesh)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo stages the tile gather through host memory: a rehearsal of the N > 1 path on a box with fewer "
+                         "GPUs than ranks (every rank then renders on --device); never a benchmark")
+    ap.add_argument("--device", type=int, default=None, help="HIP device ordinal (default LOCAL_RANK)")
     ap.add_argument("--cpu-sample-div", type=int, default=2, help="CPU baseline renders (W/div) x (H/div)")
     args = ap.parse_args()
 
@@ -84,10 +88,30 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the render path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ordinal = local_rank if args.device is None else args.device
+    torch.cuda.set_device(ordinal)
+    dev = torch.device("cuda", ordinal)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+
+    def all_reduce_sum(t):
+        if args.backend == "nccl":
+            dist.all_reduce(t)
+        else:
+            h = t.cpu()
+            dist.all_reduce(h)
+            t.copy_(h)
+
+    def all_gather(out, local):
+        if args.backend == "nccl":
+            dist.all_gather_into_tensor(out, local)
+        else:
+            parts = [torch.empty(local.numel(), dtype=local.dtype) for _ in range(world)]
+            dist.all_gather(parts, local.cpu())
+            out.copy_(torch.cat(parts))
 
     W, H = args.width, args.height
     mode = rt.TRAVERSAL_PRUNED if args.mode == "pruned" else rt.TRAVERSAL_REFERENCE
@@ -105,7 +129,7 @@ def main():
             os.makedirs(obj_dir, exist_ok=True)
         host = rt.HostScene.standin(args.scene, seed=0, obj_path_out=obj_path if want_obj else None)
         data = "synthetic"
-    scene = rt.Scene(host, device=local_rank)
+    scene = rt.Scene(host, device=ordinal)
     setup_s = time.time() - t0
 
     packed = world > 1
@@ -126,7 +150,7 @@ def main():
                            tile_rank=rank, tile_count=world, layout=params.layout)
         scene.render_device(p, rgb_u8=buf.data_ptr(), stats=st.data_ptr(), stream=stream)
         if world > 1:
-            dist.all_reduce(st)
+            all_reduce_sum(st)
         torch.cuda.synchronize()
         v = st.cpu().numpy()
         names = ["primary_rays", "reflection_rays", "shadow_rays", "shadow_occluded", "closest_hits", "node_visits",
@@ -149,7 +173,7 @@ def main():
         if i is not None:
             ev[i][1].record()
         if packed:
-            dist.all_gather_into_tensor(gathered, buf)
+            all_gather(gathered, buf)
             rt.untile(params, world, gathered.data_ptr(), frame.data_ptr(), 3, stream)
 
     for _ in range(args.warmup):
@@ -165,13 +189,14 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
-    if world > 1:
-        # the local launch covers 1/world of the frame; the roofline line is per launch on rank 0
-        pass
+    frame_crc = None
+    if rank == 0:
+        import zlib
+        frame_crc = "%08x" % zlib.crc32(frame.cpu().numpy().tobytes())
 
     # a second, short measurement of the other traversal mode (reported, never the headline)
     other_mode = rt.TRAVERSAL_REFERENCE if mode == rt.TRAVERSAL_PRUNED else rt.TRAVERSAL_PRUNED
@@ -222,6 +247,7 @@ def main():
             "bvh_depth": host.bvh_depth,
             "scene_hbm_bytes": scene.device_bytes,
             "scene_setup_seconds": round(setup_s, 2),
+            "frame_crc32": frame_crc,
         },
         "roofline": {
             "bound": "hbm",

@@ -96,7 +96,7 @@ struct DevRender {
     uint32_t n_queues;
     uint32_t total_blocks;     // 8x8 blocks of this launch
     int32_t w_inner, w_leaf, w_shade;   // weights of the wave's step choice
-    uint32_t xcd_group;                 // blocks per XCD-local run (0 = plain block order)
+    int32_t tail_lanes;                 // at most this many live lanes: run every kind of step each round
     unsigned long long *wave_log;       // diagnostics: {start, end} 100 MHz ticks per wave, or NULL
 };
 

@@ -447,10 +447,10 @@ int rtx_render_device(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8,
     r.stack_stride = block;
     // Tuning knobs (environment overrides are for experiments).
     auto knob = [](const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; };
-    r.xcd_group = (uint32_t)knob("RTX_XCD_GROUP", 0);
     r.w_inner = knob("RTX_W_INNER", 1);
     r.w_leaf = knob("RTX_W_LEAF", 2);
     r.w_shade = knob("RTX_W_SHADE", 2);
+    r.tail_lanes = knob("RTX_TAIL_LANES", 16);
     if (r.w_inner < 1 || r.w_leaf < 1 || r.w_shade < 1) return fail(RTX_ERR_INVALID, "scheduler weights must be positive");
     if (r.W == 0 || r.H == 0 || r.owned_tiles == 0) return RTX_OK;
     DeviceGuard guard(sc->device);

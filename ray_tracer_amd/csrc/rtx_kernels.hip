@@ -648,17 +648,24 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
         const unsigned long long m_shade = __ballot(L.state == ST_SHADE);
         const unsigned long long m_fetch = __ballot(L.state == ST_FETCH);
         if ((m_inner | m_leaf | m_shade | m_fetch) == 0) break;         // every lane done
-        // wave-uniform choice: the kind of step most lanes wait for (weighted)
-        const int w_inner = __popcll(m_inner) * rp.w_inner, w_leaf = __popcll(m_leaf) * rp.w_leaf,
-                  w_shade = __popcll(m_shade | m_fetch) * rp.w_shade;
-        if (w_inner >= w_leaf && w_inner >= w_shade) {
-            if (STATS && lane == 0) { rounds[0]++; lane_steps[0] += __popcll(m_inner); }
+        // wave-uniform choice: the kind of step most lanes wait for (weighted).  With only a
+        // few live lanes left (the end of the frame) every kind that has a lane waiting runs, so
+        // that no lane sits out a round.
+        const int n_inner = __popcll(m_inner), n_leaf = __popcll(m_leaf), n_shade = __popcll(m_shade | m_fetch);
+        const int w_inner = n_inner * rp.w_inner, w_leaf = n_leaf * rp.w_leaf, w_shade = n_shade * rp.w_shade;
+        const bool all_kinds = n_inner + n_leaf + n_shade <= rp.tail_lanes;
+        const bool pick_inner = w_inner >= w_leaf && w_inner >= w_shade;
+        const bool pick_leaf = !pick_inner && w_leaf >= w_shade;
+        if (pick_inner || (all_kinds && n_inner)) {
+            if (STATS && lane == 0) { rounds[0]++; lane_steps[0] += n_inner; }
             if (L.state == ST_INNER) inner_step<PRUNE, STATS>(L, sc, stack, stride, c);
-        } else if (w_leaf >= w_shade) {
-            if (STATS && lane == 0) { rounds[1]++; lane_steps[1] += __popcll(m_leaf); }
+        }
+        if (pick_leaf || (all_kinds && n_leaf)) {
+            if (STATS && lane == 0) { rounds[1]++; lane_steps[1] += __popcll(__ballot(L.state == ST_LEAF)); }
             if (L.state == ST_LEAF) leaf_step<PRUNE, STATS>(L, sc, stack, stride, c);
-        } else {
-            if (STATS && lane == 0) { rounds[2]++; lane_steps[2] += __popcll(m_shade); }
+        }
+        if ((!pick_inner && !pick_leaf) || (all_kinds && n_shade)) {
+            if (STATS && lane == 0) { rounds[2]++; lane_steps[2] += __popcll(__ballot(L.state == ST_SHADE)); }
             if (L.state == ST_SHADE) shade_step<PRUNE, STATS>(L, acc, sc, rp, scr, c);
             // hand pixels to the lanes without one, in lane order
             unsigned long long need = __ballot(L.state == ST_FETCH);

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Timing experiments on one GPU: knobs (environment, read per launch) x windows.  usage: tools/explore.py [scene] [mode]"""
-import os, sys, itertools
+"""Timing experiments on one GPU: tuning knobs (environment variables the library reads per launch).
+usage: tools/explore.py [scene] [pruned|reference] [experiments...]   experiments: weights bpc queues tile"""
+import os, sys
 sys.path.insert(0, os.getcwd())
 import torch
 import ray_tracer_amd as rt
@@ -13,6 +14,7 @@ dev = rt.Scene(host)
 buf = torch.zeros(W * H * 3, dtype=torch.uint8, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 
+
 def timeit(p, n=3):
     dev.render_device(p, rgb_u8=buf.data_ptr(), stream=st); torch.cuda.synchronize()
     ts = []
@@ -22,47 +24,32 @@ def timeit(p, n=3):
         ts.append(a.elapsed_time(b))
     return min(ts)
 
+
 def run(label, env, **kw):
-    for k, v in env.items(): os.environ[k] = str(v)
+    for k, v in env.items():
+        os.environ[k] = str(v)
     p = rt.make_params(W, H, traversal=mode, **kw)
     print(f"{label:50s} {timeit(p):8.3f} ms", flush=True)
 
-exps = sys.argv[3:] or ["chunk", "window", "weights", "tile"]
-if "chunk" in exps:
-    for ch in (64, 128, 256, 512, 1024):
-        run(f"chunk={ch}", {"RTX_CHUNK": ch, "RTX_W_INNER": 1, "RTX_W_LEAF": 1, "RTX_W_SHADE": 1})
-if "window" in exps:
-    os.environ["RTX_CHUNK"] = "1024"
-    run("window centre 1280x1280", {}, window=(1280, 2560, 440, 1720))
-    run("window centre 640x640", {}, window=(1600, 2240, 760, 1400))
-    run("window top-left 1280x440 (background)", {}, window=(0, 1280, 0, 440))
+
+exps = sys.argv[3:] or ["weights", "bpc", "queues", "tile"]
 if "weights" in exps:
-    for wi, wl, ws in ((1, 1, 1), (2, 1, 1), (1, 2, 2), (1, 4, 4), (4, 1, 1), (1, 2, 1), (1, 1, 2), (1, 8, 8), (2, 3, 3)):
-        for ch in (64, 256):
-            run(f"chunk={ch} weights inner/leaf/shade={wi}/{wl}/{ws}", {"RTX_CHUNK": ch, "RTX_W_INNER": wi, "RTX_W_LEAF": wl, "RTX_W_SHADE": ws})
-if "weights2" in exps:
     for wi, wl, ws in ((1, 1, 1), (1, 2, 2), (2, 3, 3), (1, 3, 3), (1, 2, 4), (1, 3, 2), (2, 3, 4), (3, 4, 4), (1, 4, 4), (1, 2, 3)):
         run(f"weights inner/leaf/shade={wi}/{wl}/{ws}", {"RTX_W_INNER": wi, "RTX_W_LEAF": wl, "RTX_W_SHADE": ws})
     os.environ.update(RTX_W_INNER="1", RTX_W_LEAF="2", RTX_W_SHADE="2")
 if "bpc" in exps:
     for b in (2, 3, 4, 5, 6, 8):
         run(f"blocks per CU={b}", {"RTX_BLOCKS_PER_CU": b})
-    os.environ["RTX_BLOCKS_PER_CU"] = "5"
+    del os.environ["RTX_BLOCKS_PER_CU"]
 if "queues" in exps:
     run("single queue", {"RTX_XCD_QUEUES": 0})
     for m in (1, 2, 4, 8, 16, 32):
         run(f"8 XCD queues, macro={m} tiles", {"RTX_XCD_QUEUES": 1, "RTX_MACRO": m})
-    run("single queue", {"RTX_XCD_QUEUES": 0})
     os.environ.update(RTX_XCD_QUEUES="1", RTX_MACRO="8")
-if "fetch" in exps:
-    for f in (1, 2, 4, 8, 16):
-        run(f"fetch_blocks={f}", {"RTX_FETCH_BLOCKS": f})
-    os.environ["RTX_FETCH_BLOCKS"] = "1"
-if "xcd" in exps:
-    for t in (32, 64):
-        for g in (0, 1, 2, 4, 8, 16, 32, 64, 128):
-            run(f"tile={t} xcd_group={g}", {"RTX_XCD_GROUP": g}, tile=(t, t))
-    os.environ["RTX_XCD_GROUP"] = "0"
+if "tail" in exps:
+    for t in (0, 4, 8, 16, 24, 32, 48, 64):
+        run(f"tail_lanes={t}", {"RTX_TAIL_LANES": t})
+    os.environ["RTX_TAIL_LANES"] = "16"
 if "tile" in exps:
     for t in (8, 16, 32, 64):
         run(f"tile={t}", {}, tile=(t, t))
