@@ -112,6 +112,28 @@ int rtx_host_scene_set_lights(rtx_host_scene *hs, double ambient, uint32_t n_poi
                               uint32_t n_directional, const rtx_light *directional);
 void rtx_host_scene_free(rtx_host_scene *hs);
 
+/* ---- BVH build ------------------------------------------------------------------- */
+
+enum {
+    RTX_BUILDER_HOST = 0,        /* scalar restatement of the reference builder on one host core */
+    RTX_BUILDER_DEVICE = 1       /* the same tree built by HIP kernels                           */
+};
+
+/* BVH::BVH (include/bvh.hpp:84-98: updateNodeBounds, subdivide, findBestSplitPlane,
+ * :100-162,236-305) over n_triangles triangles given as 9 doubles each.  Both builders
+ * return the reference's arrays bit for bit: nodes_out (room for 2n-1 records, *n_nodes_out
+ * used, root = 0, children in pairs in depth-first order) and indices_out (n entries).
+ * depth_out (nullable): depth of the deepest node, root = 0.  seconds_out (nullable): build
+ * time; for the device builder without the upload of the vertices and the download of the
+ * result.  device: HIP ordinal for RTX_BUILDER_DEVICE, -1 = current. */
+int rtx_bvh_build(const double *vertices, uint64_t n_triangles, int32_t builder, int32_t device,
+                  rtx_bvh_node *nodes_out, uint64_t *indices_out, uint64_t *n_nodes_out, int32_t *depth_out,
+                  double *seconds_out);
+
+/* Replaces the BVH of a loaded host scene by one built with `builder` (same arrays either
+ * way); what the Scene ctor does at include/scene.hpp:47-51. */
+int rtx_host_scene_rebuild_bvh(rtx_host_scene *hs, int32_t builder, int32_t device, double *seconds_out);
+
 /* ---- device scene --------------------------------------------------------------- */
 
 typedef struct rtx_scene rtx_scene;

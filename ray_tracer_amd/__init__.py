@@ -104,6 +104,7 @@ EXPORTS = (
     "rtx_scene_create", "rtx_scene_create_from_host", "rtx_scene_destroy", "rtx_scene_device_bytes",
     "rtx_render_params_default", "rtx_output_pixels", "rtx_render", "rtx_render_device", "rtx_untile",
     "rtx_save_ppm", "rtx_selftest_division", "rtx_last_error", "rtx_version",
+    "rtx_bvh_build", "rtx_host_scene_rebuild_bvh",
 )
 
 _lib = None
@@ -153,6 +154,9 @@ def lib() -> C.CDLL:
     L.rtx_untile.argtypes = [C.POINTER(RenderParams), C.c_int32, vp, vp, C.c_int32, vp]
     L.rtx_save_ppm.argtypes = [C.c_char_p, C.c_int32, C.c_int32, vp]
     L.rtx_selftest_division.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.rtx_bvh_build.argtypes = [C.POINTER(C.c_double), C.c_uint64, C.c_int32, C.c_int32, vp, C.POINTER(C.c_uint64),
+                                C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    L.rtx_host_scene_rebuild_bvh.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
     _lib = L
     return L
 
@@ -164,6 +168,22 @@ def _check(rc: int) -> None:
 
 def _dptr(a: np.ndarray, ctype):
     return a.ctypes.data_as(C.POINTER(ctype))
+
+
+NODE_DTYPE = np.dtype([("bmin", "<f8", 3), ("bmax", "<f8", 3), ("first", "<u8"), ("count", "<u8")])
+BUILDER_HOST, BUILDER_DEVICE = 0, 1
+
+
+def build_bvh(vertices, builder: int = BUILDER_DEVICE, device: int = -1) -> dict:
+    """BVH::BVH (include/bvh.hpp:84-98) over (n, 9) vertices: the reference's `nodes` and `indices`."""
+    v = np.ascontiguousarray(vertices, dtype=np.float64).reshape(-1, 9)
+    n = v.shape[0]
+    nodes = np.zeros(max(1, 2 * n - 1), dtype=NODE_DTYPE)
+    indices = np.zeros(n, dtype=np.uint64)
+    used, depth, seconds = C.c_uint64(), C.c_int32(), C.c_double()
+    _check(lib().rtx_bvh_build(_dptr(v, C.c_double), n, builder, device, nodes.ctypes.data, _dptr(indices, C.c_uint64),
+                               C.byref(used), C.byref(depth), C.byref(seconds)))
+    return {"nodes": nodes[: used.value].copy(), "indices": indices, "depth": depth.value, "seconds": seconds.value}
 
 
 def make_params(width: int, height: int, *, depth: int = 3, spp: int = 1, seed: int = 0,
@@ -275,6 +295,12 @@ class HostScene:
             "camera_position": np.array(d.camera_position[:]),
             "camera_rotation_deg": np.array(d.camera_rotation_deg[:]),
         }
+
+    def rebuild_bvh(self, builder: int = BUILDER_DEVICE, device: int = -1) -> float:
+        """Replaces the scene's BVH by one from `builder`; returns the build time in seconds."""
+        seconds = C.c_double()
+        _check(lib().rtx_host_scene_rebuild_bvh(self._h, builder, device, C.byref(seconds)))
+        return seconds.value
 
     def set_camera(self, position, rotation_deg) -> None:
         pos = (C.c_double * 3)(*position)

@@ -1,0 +1,670 @@
+// Binned-SAH BVH build on the GPU that produces the arrays of the reference's builder
+// (BVH::BVH / updateNodeBounds / subdivide / findBestSplitPlane,
+// include/bvh.hpp:84-162,236-305) bit for bit: same node numbering, same bounds, same
+// permutation of `indices`.
+//
+// Why that is possible in parallel:
+//  * every reduction in the reference builder is a min, a max or an integer count, so
+//    the order of accumulation does not change a value (only the sign of a zero, which is
+//    tracked separately for the stored node bounds, see `zero_sign`);
+//  * the in-place partition of bvh.hpp:128-140 is a fixed function of the left/right flags:
+//    with nL = number of "left" elements, A = [0,nL), B = [nL,m), h_k = the k-th "right"
+//    element of A from the front and l_k = the k-th "left" element of B from the back
+//    (l_0 = m), the loop moves
+//        left in A            -> stays
+//        k-th right in A      -> l_{k-1} - 1
+//        k-th left in B       -> h_k
+//        right at position nL -> l_{k*} - 1      (k* = number of rights in A)
+//        other rights in B    -> one position down
+//    (derived from: elements are examined from the front after a left and from the back
+//    after a right; lefts stay where they are examined, the t-th right examined lands at
+//    m-1-t).  Prefix counts of the flags give every rank, two scatter passes apply it;
+//  * the reference numbers nodes in depth-first order, children in pairs; an inner node's
+//    pair index follows from the number of inner nodes before it in pre-order, which is
+//    (inner nodes with a smaller `first`) + (ancestors with the same `first`).
+//
+// The tree is built breadth-first, one level per iteration, in temporary node records,
+// and renumbered at the end.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "bvh_build.h"
+
+namespace rtx {
+namespace {
+
+constexpr uint32_t kInactive = 0xffffffffu;
+constexpr int kBins = 8;
+constexpr int kBlock = 256;
+constexpr int kScanPerThread = 4;
+constexpr int kScanChunk = kBlock * kScanPerThread;   // positions per scan block
+
+// Order-preserving map double -> u64 (with -0 < +0), so that min/max run as integer atomics.
+__device__ __forceinline__ uint64_t key_of(double x) {
+    const uint64_t b = (uint64_t)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double value_of(uint64_t k) {
+    const uint64_t b = (k >> 63) ? (k ^ 0x8000000000000000ull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+constexpr uint64_t kKeyMinInit = ~0ull;   // above every key
+constexpr uint64_t kKeyMaxInit = 0ull;    // below every key
+
+// Temporary node records, structure of arrays, indexed by the breadth-first id.
+struct Nodes {
+    uint32_t *first, *count, *parent;
+    uint32_t *link;     // bit 0: is the right child; bits 1..: ancestors with the same `first`
+    uint32_t *child;    // id of the left child (right = +1); 0 = leaf
+    int32_t *axis;      // split axis chosen for this level, -1 = no split
+    double *pos;        // split position
+    uint32_t *nleft;    // "left" elements of the partition
+    uint32_t *kstar;    // "right" elements among the first nleft
+    uint64_t *box;      // [6] keys of bmin xyz, bmax xyz over the vertices
+    uint64_t *cbox;     // [6] keys of the centroid bounds
+    uint64_t *zero;     // [3] per axis: ((sequence position of the last zero coordinate + 1) << 1) | sign
+};
+
+__device__ __forceinline__ void init_node(const Nodes &nd, uint32_t t, uint32_t first, uint32_t count, uint32_t parent,
+                                          uint32_t link) {
+    nd.first[t] = first;
+    nd.count[t] = count;
+    nd.parent[t] = parent;
+    nd.link[t] = link;
+    nd.child[t] = 0;
+    nd.axis[t] = -1;
+    for (int k = 0; k < 3; k++) {
+        nd.box[6 * (size_t)t + k] = kKeyMinInit;
+        nd.box[6 * (size_t)t + 3 + k] = kKeyMaxInit;
+        nd.cbox[6 * (size_t)t + k] = kKeyMinInit;
+        nd.cbox[6 * (size_t)t + 3 + k] = kKeyMaxInit;
+        nd.zero[3 * (size_t)t + k] = 0;
+    }
+}
+
+// Triangle::centroid as the Triangle ctor computes it (include/triangle.hpp:24).
+__global__ void centroid_kernel(const double *__restrict__ V, double *__restrict__ C, uint32_t *__restrict__ idx,
+                                uint32_t *__restrict__ node_of, uint32_t n, Nodes nd) {
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p == 0) init_node(nd, 0, 0, n, 0, 0);
+    if (p >= n) return;
+    const double *v = V + 9 * (size_t)p;
+    for (int k = 0; k < 3; k++) C[3 * (size_t)p + k] = ((v[k] + v[3 + k]) + v[6 + k]) / 3;
+    idx[p] = p;
+    node_of[p] = 0;
+}
+
+__device__ __forceinline__ uint64_t shfl_up64(uint64_t v, int d) {
+    const uint32_t lo = __shfl_up((uint32_t)v, d), hi = __shfl_up((uint32_t)(v >> 32), d);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Reduction over runs of equal `node` among consecutive lanes; the last lane of a run
+// ends up with the run's result.
+template <bool IS_MIN>
+__device__ __forceinline__ uint64_t run_reduce(uint64_t v, uint32_t node, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t o = shfl_up64(v, d);
+        const uint32_t on = __shfl_up(node, d);
+        if (lane >= d && on == node) v = IS_MIN ? (o < v ? o : v) : (o > v ? o : v);
+    }
+    return v;
+}
+
+// updateNodeBounds (bvh.hpp:100-115) for every node of the new level at once, plus the
+// centroid bounds findBestSplitPlane starts with (bvh.hpp:242-250).
+__global__ void bounds_kernel(const double *__restrict__ V, const double *__restrict__ C, const uint32_t *__restrict__ idx,
+                              const uint32_t *__restrict__ node_of, uint32_t n, Nodes nd) {
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    uint32_t node = p < n ? node_of[p] : kInactive;
+    if (__ballot(node != kInactive) == 0) return;
+    uint64_t lo[3], hi[3], clo[3], chi[3], zs[3];
+    if (node != kInactive) {
+        const uint32_t t = idx[p];
+        const double *v = V + 9 * (size_t)t;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const double a = v[k], b = v[3 + k], c = v[6 + k];
+            const uint64_t ka = key_of(a), kb = key_of(b), kc = key_of(c);
+            uint64_t m = ka < kb ? ka : kb;
+            lo[k] = m < kc ? m : kc;
+            m = ka > kb ? ka : kb;
+            hi[k] = m > kc ? m : kc;
+            // the last coordinate of this triangle that is a zero, in the order v0, v1, v2
+            uint64_t z = 0;
+            if (a == 0.0) z = (((uint64_t)p * 3 + 0 + 1) << 1) | (ka >> 63);
+            if (b == 0.0) z = (((uint64_t)p * 3 + 1 + 1) << 1) | (kb >> 63);
+            if (c == 0.0) z = (((uint64_t)p * 3 + 2 + 1) << 1) | (kc >> 63);
+            zs[k] = z;
+            const uint64_t kcen = key_of(C[3 * (size_t)t + k]);
+            clo[k] = kcen;
+            chi[k] = kcen;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { lo[k] = clo[k] = kKeyMinInit; hi[k] = chi[k] = kKeyMaxInit; zs[k] = 0; }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        lo[k] = run_reduce<true>(lo[k], node, lane);
+        hi[k] = run_reduce<false>(hi[k], node, lane);
+        clo[k] = run_reduce<true>(clo[k], node, lane);
+        chi[k] = run_reduce<false>(chi[k], node, lane);
+        zs[k] = run_reduce<false>(zs[k], node, lane);
+    }
+    const uint32_t next = __shfl_down(node, 1);
+    const bool tail = lane == 63 || next != node;
+    if (tail && node != kInactive) {
+        unsigned long long *box = (unsigned long long *)nd.box + 6 * (size_t)node;
+        unsigned long long *cbox = (unsigned long long *)nd.cbox + 6 * (size_t)node;
+        unsigned long long *zero = (unsigned long long *)nd.zero + 3 * (size_t)node;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            atomicMin(box + k, (unsigned long long)lo[k]);
+            atomicMax(box + 3 + k, (unsigned long long)hi[k]);
+            atomicMin(cbox + k, (unsigned long long)clo[k]);
+            atomicMax(cbox + 3 + k, (unsigned long long)chi[k]);
+            if (zs[k]) atomicMax(zero + k, (unsigned long long)zs[k]);
+        }
+    }
+}
+
+// Per-level bin storage for the nodes [level_begin, level_end).
+struct Bins {
+    uint64_t *lo;     // [width][3 axes][kBins][3]
+    uint64_t *hi;
+    uint32_t *cnt;    // [width][3 axes][kBins]
+};
+constexpr int kBinSlots = 3 * kBins;
+
+// The binning loop of findBestSplitPlane (bvh.hpp:259-266) for all three axes of every
+// node of the level.  A wave first accumulates each run of lanes that share a node in
+// LDS and then adds the non-empty bins to the node's bins in memory.
+__global__ void bin_kernel(const double *__restrict__ V, const double *__restrict__ C, const uint32_t *__restrict__ idx,
+                           const uint32_t *__restrict__ node_of, uint32_t n, Nodes nd, Bins bins, uint32_t level_begin) {
+    __shared__ unsigned long long s_lo[kBlock / 64][kBinSlots][3], s_hi[kBlock / 64][kBinSlots][3];
+    __shared__ uint32_t s_cnt[kBlock / 64][kBinSlots];
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t node = p < n ? node_of[p] : kInactive;
+    int bin[3] = {-1, -1, -1};
+    uint64_t lo[3], hi[3];
+    if (node != kInactive) {
+        const uint32_t t = idx[p];
+        const double *v = V + 9 * (size_t)t;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const uint64_t ka = key_of(v[k]), kb = key_of(v[3 + k]), kc = key_of(v[6 + k]);
+            uint64_t m = ka < kb ? ka : kb;
+            lo[k] = m < kc ? m : kc;
+            m = ka > kb ? ka : kb;
+            hi[k] = m > kc ? m : kc;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const double cmin = value_of(nd.cbox[6 * (size_t)node + a]), cmax = value_of(nd.cbox[6 * (size_t)node + 3 + a]);
+            if (cmin == cmax) continue;                                   // bvh.hpp:252
+            const double scale = kBins / (cmax - cmin);
+            size_t b = static_cast<size_t>((C[3 * (size_t)t + a] - cmin) * scale);
+            if (b > kBins - 1) b = kBins - 1;
+            bin[a] = (int)b;
+        }
+    }
+    // runs of this wave, block-uniform number of rounds
+    uint64_t todo = __ballot(node != kInactive);
+    while (__syncthreads_or(todo != 0)) {
+        uint32_t cur = kInactive;
+        if (todo) cur = __shfl(node, __ffsll((unsigned long long)todo) - 1);
+        const bool mine = todo && node == cur;
+        if (lane < kBinSlots) {
+            s_cnt[wave][lane] = 0;
+            for (int k = 0; k < 3; k++) { s_lo[wave][lane][k] = kKeyMinInit; s_hi[wave][lane][k] = kKeyMaxInit; }
+        }
+        __syncthreads();
+        if (mine) {
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                if (bin[a] < 0) continue;
+                const int s = a * kBins + bin[a];
+                atomicAdd(&s_cnt[wave][s], 1u);
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    atomicMin(&s_lo[wave][s][k], (unsigned long long)lo[k]);
+                    atomicMax(&s_hi[wave][s][k], (unsigned long long)hi[k]);
+                }
+            }
+        }
+        __syncthreads();
+        if (todo && lane < kBinSlots && s_cnt[wave][lane]) {
+            const size_t w = (size_t)(cur - level_begin) * kBinSlots + lane;
+            atomicAdd(bins.cnt + w, s_cnt[wave][lane]);
+            for (int k = 0; k < 3; k++) {
+                atomicMin((unsigned long long *)bins.lo + 3 * w + k, s_lo[wave][lane][k]);
+                atomicMax((unsigned long long *)bins.hi + 3 * w + k, s_hi[wave][lane][k]);
+            }
+        }
+        todo &= ~__ballot(mine);
+    }
+}
+
+// AABB::area (bvh.hpp:74-78)
+__device__ __forceinline__ double half_area(const double lo[3], const double hi[3]) {
+    const double ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+    return ex * ey + ey * ez + ez * ex;
+}
+
+// findBestSplitPlane's plane sweep (bvh.hpp:268-302) and subdivide's cost test
+// (bvh.hpp:117-126), one thread per node of the level.
+__global__ void plane_kernel(Nodes nd, Bins bins, uint32_t level_begin, uint32_t level_end) {
+    const uint32_t t = level_begin + blockIdx.x * kBlock + threadIdx.x;
+    if (t >= level_end) return;
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    double best = inf, best_pos = 0;
+    int best_axis = -1;
+    for (int a = 0; a < 3; a++) {
+        const double cmin = value_of(nd.cbox[6 * (size_t)t + a]), cmax = value_of(nd.cbox[6 * (size_t)t + 3 + a]);
+        if (cmin == cmax) continue;
+        const size_t w = ((size_t)(t - level_begin) * 3 + a) * kBins;
+        double blo[kBins][3], bhi[kBins][3];
+        int bcount[kBins];
+        for (int b = 0; b < kBins; b++) {
+            bcount[b] = (int)bins.cnt[w + b];
+            for (int k = 0; k < 3; k++) {
+                blo[b][k] = value_of(bins.lo[3 * (w + b) + k]);
+                bhi[b][k] = value_of(bins.hi[3 * (w + b) + k]);
+            }
+        }
+        double larea[kBins - 1], rarea[kBins - 1];
+        int lcount[kBins - 1], rcount[kBins - 1];
+        double llo[3] = {inf, inf, inf}, lhi[3] = {-inf, -inf, -inf};
+        double rlo[3] = {inf, inf, inf}, rhi[3] = {-inf, -inf, -inf};
+        int lsum = 0, rsum = 0;
+        for (int i = 0; i < kBins - 1; i++) {
+            lsum += bcount[i];
+            lcount[i] = lsum;
+            if (bcount[i]) for (int k = 0; k < 3; k++) {                  // AABB::grow(AABB), bvh.hpp:67-72
+                llo[k] = llo[k] < blo[i][k] ? llo[k] : blo[i][k];
+                lhi[k] = lhi[k] > bhi[i][k] ? lhi[k] : bhi[i][k];
+            }
+            larea[i] = half_area(llo, lhi);
+            const int rb = kBins - 1 - i;
+            rsum += bcount[rb];
+            rcount[kBins - 2 - i] = rsum;
+            if (bcount[rb]) for (int k = 0; k < 3; k++) {
+                rlo[k] = rlo[k] < blo[rb][k] ? rlo[k] : blo[rb][k];
+                rhi[k] = rhi[k] > bhi[rb][k] ? rhi[k] : bhi[rb][k];
+            }
+            rarea[kBins - 2 - i] = half_area(rlo, rhi);
+        }
+        const double width = (cmax - cmin) / kBins;
+        for (int i = 0; i < kBins - 1; i++) {
+            const double cost = lcount[i] * larea[i] + rcount[i] * rarea[i];
+            if (cost < best) {
+                best = cost;
+                best_axis = a;
+                best_pos = cmin + width * static_cast<double>(i + 1);
+            }
+        }
+    }
+    double lo[3], hi[3];
+    for (int k = 0; k < 3; k++) { lo[k] = value_of(nd.box[6 * (size_t)t + k]); hi[k] = value_of(nd.box[6 * (size_t)t + 3 + k]); }
+    const double parent_cost = static_cast<double>(nd.count[t]) * half_area(lo, hi);   // BVHNode::cost, bvh.hpp:80-82
+    if (best >= parent_cost) best_axis = -1;
+    nd.axis[t] = best_axis;
+    nd.pos[t] = best_pos;
+}
+
+// "left" flags of the partition (bvh.hpp:131) with their exclusive prefix count inside
+// each chunk of kScanChunk positions; chunk totals go to `sums`.
+__global__ void flag_kernel(const double *__restrict__ C, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ node_of,
+                            uint32_t n, Nodes nd, uint8_t *__restrict__ flag, uint32_t *__restrict__ local,
+                            uint32_t *__restrict__ sums) {
+    __shared__ uint32_t s_wave[kBlock / 64];
+    const uint32_t base = blockIdx.x * kScanChunk + threadIdx.x * kScanPerThread;
+    uint32_t f[kScanPerThread], mine = 0;
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; k++) {
+        const uint32_t p = base + k;
+        f[k] = 0;
+        if (p < n) {
+            const uint32_t node = node_of[p];
+            if (node != kInactive) {
+                const int axis = nd.axis[node];
+                if (axis >= 0) f[k] = C[3 * (size_t)idx[p] + axis] < nd.pos[node] ? 1u : 0u;
+            }
+        }
+        mine += f[k];
+    }
+    // exclusive scan of `mine` over the block
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (int w = 0; w < kBlock / 64; w++) {
+        if (w < wave) before += s_wave[w];
+        total += s_wave[w];
+    }
+    uint32_t run = before + incl - mine;
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; k++) {
+        const uint32_t p = base + k;
+        if (p < n) { flag[p] = (uint8_t)f[k]; local[p] = run; }
+        run += f[k];
+    }
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// Same local scan for an array of counts (in place).
+__global__ void local_scan_kernel(uint32_t *__restrict__ data, uint32_t n, uint32_t *__restrict__ sums) {
+    __shared__ uint32_t s_wave[kBlock / 64];
+    const uint32_t base = blockIdx.x * kScanChunk + threadIdx.x * kScanPerThread;
+    uint32_t f[kScanPerThread], mine = 0;
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; k++) { f[k] = base + k < n ? data[base + k] : 0; mine += f[k]; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (int w = 0; w < kBlock / 64; w++) {
+        if (w < wave) before += s_wave[w];
+        total += s_wave[w];
+    }
+    uint32_t run = before + incl - mine;
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; k++) {
+        if (base + k < n) data[base + k] = run;
+        run += f[k];
+    }
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// Exclusive scan of the chunk totals by one block; sums[count] receives the grand total.
+__global__ void scan_sums_kernel(uint32_t *__restrict__ sums, uint32_t count) {
+    __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t start = 0; start < count; start += kBlock) {
+        const uint32_t i = start + threadIdx.x;
+        const uint32_t v = i < count ? sums[i] : 0;
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t before = s_carry, total = 0;
+        for (int w = 0; w < kBlock / 64; w++) {
+            if (w < wave) before += s_wave[w];
+            total += s_wave[w];
+        }
+        if (i < count) sums[i] = before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[count] = s_carry;
+}
+
+struct Prefix {
+    const uint32_t *local, *sums;
+    __device__ __forceinline__ uint32_t operator()(uint32_t p) const { return sums[p / kScanChunk] + local[p]; }
+};
+
+// Children of every node that splits (bvh.hpp:141-158); a partition that leaves one side
+// empty makes the node a leaf, but its permutation is still applied (bvh.hpp:139-141).
+__global__ void split_kernel(Nodes nd, Prefix pre, const uint8_t *__restrict__ flag, uint32_t level_begin, uint32_t level_end,
+                             uint32_t *__restrict__ next_id) {
+    const uint32_t t = level_begin + blockIdx.x * kBlock + threadIdx.x;
+    if (t >= level_end || nd.axis[t] < 0) return;
+    const uint32_t f0 = nd.first[t], m = nd.count[t];
+    const uint32_t e0 = pre(f0);
+    const uint32_t nl = pre(f0 + m - 1) + flag[f0 + m - 1] - e0;
+    uint32_t ks = 0;
+    if (nl != 0 && nl != m) ks = nl - (pre(f0 + nl) - e0);
+    nd.nleft[t] = nl;
+    nd.kstar[t] = ks;
+    if (nl == 0 || nl == m) return;
+    const uint32_t c = atomicAdd(next_id, 2u);
+    nd.child[t] = c;
+    init_node(nd, c, f0, nl, t, ((nd.link[t] >> 1) + 1) << 1);
+    init_node(nd, c + 1, f0 + nl, m - nl, t, 1u);
+}
+
+// Positions (relative to the node) of the k-th right element of A and of the k-th left
+// element of B from the back.
+__global__ void holes_kernel(const uint32_t *__restrict__ node_of, uint32_t n, Nodes nd, Prefix pre,
+                             const uint8_t *__restrict__ flag, uint32_t *__restrict__ holes, uint32_t *__restrict__ fills) {
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t t = node_of[p];
+    if (t == kInactive || nd.axis[t] < 0) return;
+    const uint32_t f0 = nd.first[t], nl = nd.nleft[t], rel = p - f0, f = flag[p];
+    const uint32_t lefts_to_here = pre(p) + f - pre(f0);
+    if (rel < nl && !f) holes[f0 + (rel + 1 - lefts_to_here) - 1] = rel;
+    if (rel >= nl && f) fills[f0 + (nl - lefts_to_here + 1) - 1] = rel;
+}
+
+// Applies the partition's permutation and hands every position to its child node.
+__global__ void permute_kernel(const uint32_t *__restrict__ idx, const uint32_t *__restrict__ node_of, uint32_t n, Nodes nd,
+                               Prefix pre, const uint8_t *__restrict__ flag, const uint32_t *__restrict__ holes,
+                               const uint32_t *__restrict__ fills, uint32_t *__restrict__ idx_out,
+                               uint32_t *__restrict__ node_out) {
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t t = node_of[p];
+    if (t == kInactive || nd.axis[t] < 0) {
+        idx_out[p] = idx[p];
+        node_out[p] = kInactive;
+        return;
+    }
+    const uint32_t f0 = nd.first[t], m = nd.count[t], nl = nd.nleft[t], ks = nd.kstar[t], rel = p - f0, f = flag[p];
+    const uint32_t lefts_to_here = pre(p) + f - pre(f0);
+    uint32_t dest;
+    if (rel < nl) {
+        if (f) dest = rel;
+        else {
+            const uint32_t k = rel + 1 - lefts_to_here;
+            dest = (k == 1 ? m : fills[f0 + k - 2]) - 1;
+        }
+    } else {
+        if (f) dest = holes[f0 + (nl - lefts_to_here + 1) - 1];
+        else if (rel == nl) dest = (ks == 0 ? m : fills[f0 + ks - 1]) - 1;
+        else dest = rel - 1;
+    }
+    idx_out[f0 + dest] = idx[p];
+    const uint32_t c = nd.child[t];
+    node_out[f0 + dest] = c ? (dest < nl ? c : c + 1) : kInactive;
+}
+
+// Number of inner nodes that start at each position.
+__global__ void inner_count_kernel(Nodes nd, uint32_t n_nodes, uint32_t *__restrict__ starts) {
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    if (t < n_nodes && nd.child[t]) atomicAdd(starts + nd.first[t], 1u);
+}
+
+// Stored bound of a node: the reduced value, with the sign of a zero taken from the
+// last zero coordinate in the reference's accumulation order (its min/max keep the
+// later operand on a tie, include/vector3.hpp:92-106).
+__device__ __forceinline__ double zero_sign(double v, uint64_t tracker) {
+    if (v != 0.0) return v;
+    return (tracker & 1) ? 0.0 : -0.0;
+}
+
+// Writes the reference's node array: pre-order pair numbering.
+__global__ void emit_kernel(Nodes nd, uint32_t n_nodes, Prefix pre, rtx_bvh_node *__restrict__ out) {
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= n_nodes) return;
+    uint64_t where = 0;
+    if (t != 0) {
+        const uint32_t par = nd.parent[t];
+        const uint64_t rank = (uint64_t)pre(nd.first[par]) + (nd.link[par] >> 1);
+        where = 1 + 2 * rank + (nd.link[t] & 1);
+    }
+    rtx_bvh_node o;
+    for (int k = 0; k < 3; k++) {
+        o.bmin[k] = zero_sign(value_of(nd.box[6 * (size_t)t + k]), nd.zero[3 * (size_t)t + k]);
+        o.bmax[k] = zero_sign(value_of(nd.box[6 * (size_t)t + 3 + k]), nd.zero[3 * (size_t)t + k]);
+    }
+    if (nd.child[t]) {
+        o.first = 1 + 2 * ((uint64_t)pre(nd.first[t]) + (nd.link[t] >> 1));
+        o.count = 0;
+    } else {
+        o.first = nd.first[t];
+        o.count = nd.count[t];
+    }
+    out[where] = o;
+}
+
+__global__ void widen_kernel(const uint32_t *__restrict__ idx, uint64_t *__restrict__ out, uint32_t n) {
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p < n) out[p] = idx[p];
+}
+
+struct DeviceBuffers {
+    std::vector<void *> all;
+    ~DeviceBuffers() { for (void *p : all) (void)hipFree(p); }
+    template <typename T>
+    hipError_t get(T **out, size_t count) {
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, (count ? count : 1) * sizeof(T));
+        if (e == hipSuccess) all.push_back(p);
+        *out = static_cast<T *>(p);
+        return e;
+    }
+};
+
+inline uint32_t blocks_for(uint64_t items, uint32_t per_block = kBlock) { return (uint32_t)((items + per_block - 1) / per_block); }
+
+}  // namespace
+
+#define HIP_TRY_B(expr)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) { *err = std::string(#expr) + ": " + hipGetErrorString(e_); return RTX_ERR_DEVICE; } \
+    } while (0)
+
+int build_bvh_device(const double *vertices, uint64_t n64, rtx_bvh_node *nodes_out, uint64_t *indices_out,
+                     uint64_t *n_nodes_out, int32_t *depth_out, double *device_ms_out, std::string *err) {
+    if (n64 == 0) { *err = "cannot build a BVH over zero triangles"; return RTX_ERR_INVALID; }
+    if (n64 >= (1ull << 28)) { *err = "more than 2^28 triangles"; return RTX_ERR_UNSUPPORTED; }
+    const uint32_t n = (uint32_t)n64;
+    const uint32_t cap = 2 * n - 1;
+    const uint32_t chunks = blocks_for(n, kScanChunk);
+    DeviceBuffers buf;
+    double *V, *C;
+    uint32_t *idx[2], *node_of[2], *local, *sums, *holes, *fills, *next_id, *starts;
+    uint8_t *flag;
+    Nodes nd;
+    HIP_TRY_B(buf.get(&V, 9 * (size_t)n));
+    HIP_TRY_B(buf.get(&C, 3 * (size_t)n));
+    for (int k = 0; k < 2; k++) { HIP_TRY_B(buf.get(&idx[k], n)); HIP_TRY_B(buf.get(&node_of[k], n)); }
+    HIP_TRY_B(buf.get(&local, n));
+    HIP_TRY_B(buf.get(&sums, (size_t)chunks + 1));
+    HIP_TRY_B(buf.get(&holes, n));
+    HIP_TRY_B(buf.get(&fills, n));
+    HIP_TRY_B(buf.get(&flag, n));
+    HIP_TRY_B(buf.get(&next_id, 1));
+    HIP_TRY_B(buf.get(&starts, n));
+    HIP_TRY_B(buf.get(&nd.first, cap)); HIP_TRY_B(buf.get(&nd.count, cap)); HIP_TRY_B(buf.get(&nd.parent, cap));
+    HIP_TRY_B(buf.get(&nd.link, cap)); HIP_TRY_B(buf.get(&nd.child, cap)); HIP_TRY_B(buf.get(&nd.axis, cap));
+    HIP_TRY_B(buf.get(&nd.pos, cap)); HIP_TRY_B(buf.get(&nd.nleft, cap)); HIP_TRY_B(buf.get(&nd.kstar, cap));
+    HIP_TRY_B(buf.get(&nd.box, 6 * (size_t)cap)); HIP_TRY_B(buf.get(&nd.cbox, 6 * (size_t)cap));
+    HIP_TRY_B(buf.get(&nd.zero, 3 * (size_t)cap));
+    rtx_bvh_node *d_out;
+    uint64_t *d_indices;
+    HIP_TRY_B(buf.get(&d_out, cap));
+    HIP_TRY_B(buf.get(&d_indices, n));
+
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0, ev1;
+    HIP_TRY_B(hipEventCreate(&ev0));
+    HIP_TRY_B(hipEventCreate(&ev1));
+    struct EventGuard { hipEvent_t a, b; ~EventGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } guard{ev0, ev1};
+    HIP_TRY_B(hipMemcpy(V, vertices, 9 * (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY_B(hipEventRecord(ev0, stream));
+
+    const uint32_t pos_blocks = blocks_for(n);
+    uint32_t one = 1;
+    HIP_TRY_B(hipMemcpyAsync(next_id, &one, sizeof one, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(centroid_kernel, dim3(pos_blocks), dim3(kBlock), 0, stream, V, C, idx[0], node_of[0], n, nd);
+    hipLaunchKernelGGL(bounds_kernel, dim3(pos_blocks), dim3(kBlock), 0, stream, V, C, idx[0], node_of[0], n, nd);
+
+    Bins bins{nullptr, nullptr, nullptr};
+    uint64_t bins_width = 0;
+    const Prefix pre{local, sums};
+    uint32_t level_begin = 0, level_end = 1;
+    int cur = 0, depth = 0;
+    for (;; depth++) {
+        const uint32_t width = level_end - level_begin;
+        if (width > bins_width) {
+            bins_width = std::max<uint64_t>(width, 2 * bins_width);
+            bins_width = std::min<uint64_t>(bins_width, cap);
+            HIP_TRY_B(buf.get(&bins.lo, bins_width * kBinSlots * 3));
+            HIP_TRY_B(buf.get(&bins.hi, bins_width * kBinSlots * 3));
+            HIP_TRY_B(buf.get(&bins.cnt, bins_width * kBinSlots));
+        }
+        HIP_TRY_B(hipMemsetAsync(bins.lo, 0xff, (size_t)width * kBinSlots * 3 * sizeof(uint64_t), stream));
+        HIP_TRY_B(hipMemsetAsync(bins.hi, 0x00, (size_t)width * kBinSlots * 3 * sizeof(uint64_t), stream));
+        HIP_TRY_B(hipMemsetAsync(bins.cnt, 0x00, (size_t)width * kBinSlots * sizeof(uint32_t), stream));
+        const uint32_t node_blocks = blocks_for(width);
+        hipLaunchKernelGGL(bin_kernel, dim3(pos_blocks), dim3(kBlock), 0, stream, V, C, idx[cur], node_of[cur], n, nd, bins, level_begin);
+        hipLaunchKernelGGL(plane_kernel, dim3(node_blocks), dim3(kBlock), 0, stream, nd, bins, level_begin, level_end);
+        hipLaunchKernelGGL(flag_kernel, dim3(chunks), dim3(kBlock), 0, stream, C, idx[cur], node_of[cur], n, nd, flag, local, sums);
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, stream, sums, chunks);
+        hipLaunchKernelGGL(split_kernel, dim3(node_blocks), dim3(kBlock), 0, stream, nd, pre, flag, level_begin, level_end, next_id);
+        hipLaunchKernelGGL(holes_kernel, dim3(pos_blocks), dim3(kBlock), 0, stream, node_of[cur], n, nd, pre, flag, holes, fills);
+        hipLaunchKernelGGL(permute_kernel, dim3(pos_blocks), dim3(kBlock), 0, stream, idx[cur], node_of[cur], n, nd, pre, flag, holes,
+                           fills, idx[cur ^ 1], node_of[cur ^ 1]);
+        cur ^= 1;
+        uint32_t next = 0;
+        HIP_TRY_B(hipMemcpyAsync(&next, next_id, sizeof next, hipMemcpyDeviceToHost, stream));
+        HIP_TRY_B(hipStreamSynchronize(stream));
+        if (next > cap) { *err = "BVH build: node counter overran its bound"; return RTX_ERR_DEVICE; }
+        if (next == level_end) break;
+        level_begin = level_end;
+        level_end = next;
+        hipLaunchKernelGGL(bounds_kernel, dim3(pos_blocks), dim3(kBlock), 0, stream, V, C, idx[cur], node_of[cur], n, nd);
+    }
+    const uint32_t n_nodes = level_end;
+    HIP_TRY_B(hipMemsetAsync(starts, 0, (size_t)n * sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(inner_count_kernel, dim3(blocks_for(n_nodes)), dim3(kBlock), 0, stream, nd, n_nodes, starts);
+    hipLaunchKernelGGL(local_scan_kernel, dim3(chunks), dim3(kBlock), 0, stream, starts, n, sums);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, stream, sums, chunks);
+    hipLaunchKernelGGL(emit_kernel, dim3(blocks_for(n_nodes)), dim3(kBlock), 0, stream, nd, n_nodes, Prefix{starts, sums}, d_out);
+    hipLaunchKernelGGL(widen_kernel, dim3(pos_blocks), dim3(kBlock), 0, stream, idx[cur], d_indices, n);
+    HIP_TRY_B(hipEventRecord(ev1, stream));
+    HIP_TRY_B(hipGetLastError());
+    HIP_TRY_B(hipMemcpy(nodes_out, d_out, (size_t)n_nodes * sizeof(rtx_bvh_node), hipMemcpyDeviceToHost));
+    HIP_TRY_B(hipMemcpy(indices_out, d_indices, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    float ms = 0;
+    HIP_TRY_B(hipEventElapsedTime(&ms, ev0, ev1));
+    *n_nodes_out = n_nodes;
+    *depth_out = depth;
+    *device_ms_out = ms;
+    return RTX_OK;
+}
+
+}  // namespace rtx

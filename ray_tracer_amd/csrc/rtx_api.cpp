@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "bvh_build.h"
 #include "device_layout.h"
 #include "host_scene.hpp"
 #include "rtx.h"
@@ -255,6 +256,60 @@ int rtx_host_scene_set_lights(rtx_host_scene *hs, double ambient, uint32_t n_poi
 }
 
 void rtx_host_scene_free(rtx_host_scene *hs) { delete hs; }
+
+// ------------------------------------------------------------------ BVH build
+int rtx_bvh_build(const double *vertices, uint64_t n, int32_t builder, int32_t device, rtx_bvh_node *nodes_out,
+                  uint64_t *indices_out, uint64_t *n_nodes_out, int32_t *depth_out, double *seconds_out) {
+    if (!vertices || !nodes_out || !indices_out || !n_nodes_out) return fail(RTX_ERR_INVALID, "NULL argument");
+    if (n == 0) return fail(RTX_ERR_INVALID, "cannot build a BVH over zero triangles");
+    std::string err;
+    if (builder == RTX_BUILDER_HOST) {
+        rtx::HostScene s;
+        s.vertices.assign(vertices, vertices + 9 * n);
+        s.colors.assign(3 * n, 0);
+        s.specularity.assign(n, -1);
+        s.reflectivity.assign(n, -1.0);
+        rtx::setup_triangles(&s, false);
+        if (int rc = rtx::build_bvh(&s, &err)) return fail(rc, err);
+        std::copy(s.nodes.begin(), s.nodes.end(), nodes_out);
+        std::copy(s.indices.begin(), s.indices.end(), indices_out);
+        *n_nodes_out = s.nodes.size();
+        if (depth_out) *depth_out = s.bvh_depth;
+        if (seconds_out) *seconds_out = s.bvh_seconds;
+        return RTX_OK;
+    }
+    if (builder != RTX_BUILDER_DEVICE) return fail(RTX_ERR_INVALID, "unknown BVH builder");
+    int dev = device;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    DeviceGuard guard(dev);
+    if (!guard.ok) return fail(RTX_ERR_DEVICE, "cannot select the HIP device");
+    int32_t depth = 0;
+    double ms = 0;
+    if (int rc = rtx::build_bvh_device(vertices, n, nodes_out, indices_out, n_nodes_out, &depth, &ms, &err)) return fail(rc, err);
+    if (depth_out) *depth_out = depth;
+    if (seconds_out) *seconds_out = ms * 1e-3;
+    return RTX_OK;
+}
+
+int rtx_host_scene_rebuild_bvh(rtx_host_scene *hs, int32_t builder, int32_t device, double *seconds_out) {
+    if (!hs) return fail(RTX_ERR_INVALID, "NULL argument");
+    rtx::HostScene &s = hs->s;
+    const uint64_t n = s.n_triangles();
+    if (n == 0) return fail(RTX_ERR_INVALID, "scene has no triangles");
+    std::vector<rtx_bvh_node> nodes(2 * n - 1);
+    std::vector<uint64_t> indices(n);
+    uint64_t used = 0;
+    int32_t depth = 0;
+    double seconds = 0;
+    if (int rc = rtx_bvh_build(s.vertices.data(), n, builder, device, nodes.data(), indices.data(), &used, &depth, &seconds)) return rc;
+    nodes.resize(used);
+    s.nodes.swap(nodes);
+    s.indices.swap(indices);
+    s.bvh_depth = depth;
+    s.bvh_seconds = seconds;
+    if (seconds_out) *seconds_out = seconds;
+    return RTX_OK;
+}
 
 // ------------------------------------------------------------------ device scenes
 int rtx_scene_create_from_host(const rtx_host_scene *hs, int32_t device, rtx_scene **out) {

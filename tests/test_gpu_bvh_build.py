@@ -1,0 +1,84 @@
+"""The GPU BVH builder against the host restatement of the reference builder
+(include/bvh.hpp:84-162,236-305), which the CPU tests pin to the reference's own arrays:
+node records and `indices` must be byte-identical."""
+import os
+
+import numpy as np
+import pytest
+
+import ray_tracer_amd as rt
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def same_tree(vertices):
+    host = rt.build_bvh(vertices, rt.BUILDER_HOST)
+    dev = rt.build_bvh(vertices, rt.BUILDER_DEVICE)
+    assert dev["nodes"].shape == host["nodes"].shape
+    assert np.array_equal(dev["indices"], host["indices"])
+    assert dev["nodes"].tobytes() == host["nodes"].tobytes()
+    assert dev["depth"] == host["depth"]
+    return host, dev
+
+
+def test_teapot_tree_is_identical():
+    hs = rt.HostScene.load_obj(os.path.join(HERE, "golden", "teapot.obj"), "teapot")
+    host, _ = same_tree(hs.arrays()["vertices"])
+    assert host["nodes"].shape[0] == 12541
+
+
+@pytest.mark.parametrize("n,seed", [(1, 1), (2, 2), (3, 3), (17, 4), (64, 5), (65, 6), (1000, 7), (4097, 8), (50000, 9)])
+def test_random_soups(n, seed):
+    rng = np.random.default_rng(seed)
+    v = rng.uniform(-4, 4, size=(n, 1, 3)) + rng.uniform(-1.2, 1.2, size=(n, 3, 3))
+    same_tree(v.reshape(n, 9))
+
+
+def test_lattice_with_ties_zeros_and_duplicates():
+    """Coordinates on a coarse integer lattice around the origin: many equal centroids, many
+    zero coordinates of both signs, duplicate triangles, empty bins and one-sided partitions."""
+    rng = np.random.default_rng(11)
+    v = rng.integers(-2, 3, size=(3000, 9)).astype(np.float64)
+    v[rng.random(v.shape) < 0.2] = -0.0
+    v[1000:1500] = v[:500]
+    same_tree(v)
+
+
+def test_clustered_and_degenerate_triangles():
+    rng = np.random.default_rng(12)
+    centers = rng.normal(size=(20, 1, 3)) * 50
+    v = (centers + rng.normal(size=(20, 400, 3)) * 0.01).reshape(-1, 1, 3) + rng.normal(size=(8000, 3, 3)) * 1e-3
+    v = v.reshape(-1, 9)
+    v[::7, 3:6] = v[::7, 0:3]          # zero-area triangles
+    v[::11] = np.tile(v[::11, :3], 3)  # points
+    same_tree(v)
+
+
+def test_sorted_slivers_make_a_deep_tree():
+    """Geometrically growing spacing: every split peels off a few triangles, so the tree is a long chain."""
+    x = np.cumsum(1.5 ** np.arange(60))
+    v = np.zeros((60, 9))
+    v[:, 0], v[:, 3], v[:, 6] = x, x + 0.1, x
+    v[:, 4], v[:, 8] = 0.1, 0.1
+    host, _ = same_tree(v)
+    assert host["depth"] > 12
+
+
+def test_standin_bunny_tree_and_render():
+    hs = rt.HostScene.standin("bunny", 20010, seed=3)
+    before = hs.arrays()
+    hs.rebuild_bvh(rt.BUILDER_DEVICE)
+    after = hs.arrays()
+    assert after["nodes"].tobytes() == before["nodes"].tobytes()
+    assert np.array_equal(after["indices"], before["indices"])
+    frame = rt.Scene(hs).render(96, 54, traversal=rt.TRAVERSAL_PRUNED)
+    assert (frame.hit >= 0).any()
+
+
+def test_full_size_dragon_tree():
+    hs = rt.HostScene.standin("dragon", seed=1)
+    a = hs.arrays()
+    dev = rt.build_bvh(a["vertices"], rt.BUILDER_DEVICE)
+    assert dev["nodes"].tobytes() == a["nodes"].tobytes()
+    assert np.array_equal(dev["indices"], a["indices"])
