@@ -41,8 +41,13 @@ namespace {
 constexpr uint32_t kInactive = 0xffffffffu;
 constexpr int kBins = 8;
 constexpr int kBlock = 256;
+constexpr int kFat = 1024;      // block size of the kernels that reduce into per-node records
 constexpr int kScanPerThread = 4;
 constexpr int kScanChunk = kBlock * kScanPerThread;   // positions per scan block
+// A node with at most this many triangles leaves the level-by-level passes; one wave
+// builds its whole subtree (subtree_kernel).
+constexpr uint32_t kSmall = 64;
+constexpr uint32_t kSerialMembers = 8;   // subtree nodes up to this size are reduced lane by lane
 
 // Order-preserving map double -> u64 (with -0 < +0), so that min/max run as integer atomics.
 __device__ __forceinline__ uint64_t key_of(double x) {
@@ -119,61 +124,94 @@ __device__ __forceinline__ uint64_t run_reduce(uint64_t v, uint32_t node, int la
 
 // updateNodeBounds (bvh.hpp:100-115) for every node of the new level at once, plus the
 // centroid bounds findBestSplitPlane starts with (bvh.hpp:242-250).
-__global__ void bounds_kernel(const double *__restrict__ V, const double *__restrict__ C, const uint32_t *__restrict__ idx,
-                              const uint32_t *__restrict__ node_of, uint32_t n, Nodes nd) {
-    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+// A block walks `tiles_per_block` consecutive tiles of kFat positions.  Tiles that lie
+// inside one node are accumulated in LDS across tiles, so that a large node receives one
+// set of atomics per block; other tiles send one set per run of lanes that share a node.
+__global__ __launch_bounds__(kFat) void bounds_kernel(const double *__restrict__ V, const double *__restrict__ C,
+                                                      const uint32_t *__restrict__ idx, const uint32_t *__restrict__ node_of,
+                                                      uint32_t n, Nodes nd, uint32_t tiles_per_block) {
+    // 0-2 bmin, 3-5 bmax, 6-8 centroid min, 9-11 centroid max, 12-14 zero trackers
+    __shared__ unsigned long long s_acc[15];
     const int lane = threadIdx.x & 63;
-    uint32_t node = p < n ? node_of[p] : kInactive;
-    if (__ballot(node != kInactive) == 0) return;
-    uint64_t lo[3], hi[3], clo[3], chi[3], zs[3];
-    if (node != kInactive) {
-        const uint32_t t = idx[p];
-        const double *v = V + 9 * (size_t)t;
+    const bool acc_is_min = threadIdx.x < 3 || (threadIdx.x >= 6 && threadIdx.x < 9);
+    if (threadIdx.x < 15) s_acc[threadIdx.x] = acc_is_min ? kKeyMinInit : kKeyMaxInit;
+    uint32_t acc_node = kInactive;                   // block-uniform
+    auto flush = [&]() {
+        __syncthreads();
+        if (acc_node != kInactive && threadIdx.x < 15) {
+            const unsigned long long v = s_acc[threadIdx.x];
+            unsigned long long *dst = threadIdx.x < 6    ? (unsigned long long *)nd.box + 6 * (size_t)acc_node + threadIdx.x
+                                      : threadIdx.x < 12 ? (unsigned long long *)nd.cbox + 6 * (size_t)acc_node + (threadIdx.x - 6)
+                                                         : (unsigned long long *)nd.zero + 3 * (size_t)acc_node + (threadIdx.x - 12);
+            if (acc_is_min) atomicMin(dst, v); else if (v) atomicMax(dst, v);
+            s_acc[threadIdx.x] = acc_is_min ? kKeyMinInit : kKeyMaxInit;
+        }
+        __syncthreads();
+    };
+    __syncthreads();
+    for (uint32_t tile = 0; tile < tiles_per_block; tile++) {
+        const uint64_t start = ((uint64_t)blockIdx.x * tiles_per_block + tile) * kFat;
+        if (start >= n) break;
+        const uint32_t p = (uint32_t)start + threadIdx.x;
+        const uint32_t node = p < n ? node_of[p] : kInactive;
+        if (!__syncthreads_or(node != kInactive)) continue;
+        const uint32_t tile_node = node_of[start];
+        const bool uniform = __syncthreads_and(p >= n || node == tile_node) && tile_node != kInactive;
+        if (!uniform || acc_node != tile_node) {
+            flush();
+            acc_node = uniform ? tile_node : kInactive;
+        }
+        uint64_t lo[3], hi[3], clo[3], chi[3], zs[3];
+        if (node != kInactive) {
+            const uint32_t t = idx[p];
+            const double *v = V + 9 * (size_t)t;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const double a = v[k], b = v[3 + k], c = v[6 + k];
+                const uint64_t ka = key_of(a), kb = key_of(b), kc = key_of(c);
+                uint64_t m = ka < kb ? ka : kb;
+                lo[k] = m < kc ? m : kc;
+                m = ka > kb ? ka : kb;
+                hi[k] = m > kc ? m : kc;
+                // the last coordinate of this triangle that is a zero, in the order v0, v1, v2
+                uint64_t z = 0;
+                if (a == 0.0) z = (((uint64_t)p * 3 + 0 + 1) << 1) | (ka >> 63);
+                if (b == 0.0) z = (((uint64_t)p * 3 + 1 + 1) << 1) | (kb >> 63);
+                if (c == 0.0) z = (((uint64_t)p * 3 + 2 + 1) << 1) | (kc >> 63);
+                zs[k] = z;
+                const uint64_t kcen = key_of(C[3 * (size_t)t + k]);
+                clo[k] = kcen;
+                chi[k] = kcen;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { lo[k] = clo[k] = kKeyMinInit; hi[k] = chi[k] = kKeyMaxInit; zs[k] = 0; }
+        }
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            const double a = v[k], b = v[3 + k], c = v[6 + k];
-            const uint64_t ka = key_of(a), kb = key_of(b), kc = key_of(c);
-            uint64_t m = ka < kb ? ka : kb;
-            lo[k] = m < kc ? m : kc;
-            m = ka > kb ? ka : kb;
-            hi[k] = m > kc ? m : kc;
-            // the last coordinate of this triangle that is a zero, in the order v0, v1, v2
-            uint64_t z = 0;
-            if (a == 0.0) z = (((uint64_t)p * 3 + 0 + 1) << 1) | (ka >> 63);
-            if (b == 0.0) z = (((uint64_t)p * 3 + 1 + 1) << 1) | (kb >> 63);
-            if (c == 0.0) z = (((uint64_t)p * 3 + 2 + 1) << 1) | (kc >> 63);
-            zs[k] = z;
-            const uint64_t kcen = key_of(C[3 * (size_t)t + k]);
-            clo[k] = kcen;
-            chi[k] = kcen;
+            lo[k] = run_reduce<true>(lo[k], node, lane);
+            hi[k] = run_reduce<false>(hi[k], node, lane);
+            clo[k] = run_reduce<true>(clo[k], node, lane);
+            chi[k] = run_reduce<false>(chi[k], node, lane);
+            zs[k] = run_reduce<false>(zs[k], node, lane);
         }
-    } else {
+        const uint32_t next = __shfl_down(node, 1);
+        const bool tail = lane == 63 || next != node;
+        if (tail && node != kInactive) {
+            unsigned long long *box = uniform ? s_acc : (unsigned long long *)nd.box + 6 * (size_t)node;
+            unsigned long long *cbox = uniform ? s_acc + 6 : (unsigned long long *)nd.cbox + 6 * (size_t)node;
+            unsigned long long *zero = uniform ? s_acc + 12 : (unsigned long long *)nd.zero + 3 * (size_t)node;
 #pragma unroll
-        for (int k = 0; k < 3; k++) { lo[k] = clo[k] = kKeyMinInit; hi[k] = chi[k] = kKeyMaxInit; zs[k] = 0; }
-    }
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        lo[k] = run_reduce<true>(lo[k], node, lane);
-        hi[k] = run_reduce<false>(hi[k], node, lane);
-        clo[k] = run_reduce<true>(clo[k], node, lane);
-        chi[k] = run_reduce<false>(chi[k], node, lane);
-        zs[k] = run_reduce<false>(zs[k], node, lane);
-    }
-    const uint32_t next = __shfl_down(node, 1);
-    const bool tail = lane == 63 || next != node;
-    if (tail && node != kInactive) {
-        unsigned long long *box = (unsigned long long *)nd.box + 6 * (size_t)node;
-        unsigned long long *cbox = (unsigned long long *)nd.cbox + 6 * (size_t)node;
-        unsigned long long *zero = (unsigned long long *)nd.zero + 3 * (size_t)node;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            atomicMin(box + k, (unsigned long long)lo[k]);
-            atomicMax(box + 3 + k, (unsigned long long)hi[k]);
-            atomicMin(cbox + k, (unsigned long long)clo[k]);
-            atomicMax(cbox + 3 + k, (unsigned long long)chi[k]);
-            if (zs[k]) atomicMax(zero + k, (unsigned long long)zs[k]);
+            for (int k = 0; k < 3; k++) {
+                atomicMin(box + k, (unsigned long long)lo[k]);
+                atomicMax(box + 3 + k, (unsigned long long)hi[k]);
+                atomicMin(cbox + k, (unsigned long long)clo[k]);
+                atomicMax(cbox + 3 + k, (unsigned long long)chi[k]);
+                if (zs[k]) atomicMax(zero + k, (unsigned long long)zs[k]);
+            }
         }
     }
+    flush();
 }
 
 // Per-level bin storage for the nodes [level_begin, level_end).
@@ -185,73 +223,108 @@ struct Bins {
 constexpr int kBinSlots = 3 * kBins;
 
 // The binning loop of findBestSplitPlane (bvh.hpp:259-266) for all three axes of every
-// node of the level.  A wave first accumulates each run of lanes that share a node in
-// LDS and then adds the non-empty bins to the node's bins in memory.
-__global__ void bin_kernel(const double *__restrict__ V, const double *__restrict__ C, const uint32_t *__restrict__ idx,
-                           const uint32_t *__restrict__ node_of, uint32_t n, Nodes nd, Bins bins, uint32_t level_begin) {
-    __shared__ unsigned long long s_lo[kBlock / 64][kBinSlots][3], s_hi[kBlock / 64][kBinSlots][3];
-    __shared__ uint32_t s_cnt[kBlock / 64][kBinSlots];
-    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+// node of the level.  Same tiling as bounds_kernel: tiles inside one node fill one set of
+// bins in LDS per block; in other tiles each wave accumulates every run of lanes that
+// share a node in its own LDS bins and adds the non-empty ones to the node's bins.
+__global__ __launch_bounds__(kFat) void bin_kernel(const double *__restrict__ V, const double *__restrict__ C,
+                                                   const uint32_t *__restrict__ idx, const uint32_t *__restrict__ node_of,
+                                                   uint32_t n, Nodes nd, Bins bins, uint32_t level_begin,
+                                                   uint32_t tiles_per_block) {
+    constexpr int kWaves = kFat / 64;
+    __shared__ unsigned long long s_lo[kWaves + 1][kBinSlots][3], s_hi[kWaves + 1][kBinSlots][3];   // [kWaves] = the block's
+    __shared__ uint32_t s_cnt[kWaves + 1][kBinSlots];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t node = p < n ? node_of[p] : kInactive;
-    int bin[3] = {-1, -1, -1};
-    uint64_t lo[3], hi[3];
-    if (node != kInactive) {
-        const uint32_t t = idx[p];
-        const double *v = V + 9 * (size_t)t;
-#pragma unroll
+    auto reset = [&](int which, int slot) {
+        s_cnt[which][slot] = 0;
+        for (int k = 0; k < 3; k++) { s_lo[which][slot][k] = kKeyMinInit; s_hi[which][slot][k] = kKeyMaxInit; }
+    };
+    auto send = [&](int which, int slot, uint32_t node) {
+        if (!s_cnt[which][slot]) return;
+        const size_t w = (size_t)(node - level_begin) * kBinSlots + slot;
+        atomicAdd(bins.cnt + w, s_cnt[which][slot]);
         for (int k = 0; k < 3; k++) {
-            const uint64_t ka = key_of(v[k]), kb = key_of(v[3 + k]), kc = key_of(v[6 + k]);
-            uint64_t m = ka < kb ? ka : kb;
-            lo[k] = m < kc ? m : kc;
-            m = ka > kb ? ka : kb;
-            hi[k] = m > kc ? m : kc;
+            atomicMin((unsigned long long *)bins.lo + 3 * w + k, s_lo[which][slot][k]);
+            atomicMax((unsigned long long *)bins.hi + 3 * w + k, s_hi[which][slot][k]);
         }
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            const double cmin = value_of(nd.cbox[6 * (size_t)node + a]), cmax = value_of(nd.cbox[6 * (size_t)node + 3 + a]);
-            if (cmin == cmax) continue;                                   // bvh.hpp:252
-            const double scale = kBins / (cmax - cmin);
-            size_t b = static_cast<size_t>((C[3 * (size_t)t + a] - cmin) * scale);
-            if (b > kBins - 1) b = kBins - 1;
-            bin[a] = (int)b;
-        }
-    }
-    // runs of this wave, block-uniform number of rounds
-    uint64_t todo = __ballot(node != kInactive);
-    while (__syncthreads_or(todo != 0)) {
-        uint32_t cur = kInactive;
-        if (todo) cur = __shfl(node, __ffsll((unsigned long long)todo) - 1);
-        const bool mine = todo && node == cur;
-        if (lane < kBinSlots) {
-            s_cnt[wave][lane] = 0;
-            for (int k = 0; k < 3; k++) { s_lo[wave][lane][k] = kKeyMinInit; s_hi[wave][lane][k] = kKeyMaxInit; }
+    };
+    uint32_t acc_node = kInactive;                   // block-uniform
+    auto flush = [&]() {
+        __syncthreads();
+        if (acc_node != kInactive && threadIdx.x < kBinSlots) {
+            send(kWaves, threadIdx.x, acc_node);
+            reset(kWaves, threadIdx.x);
         }
         __syncthreads();
-        if (mine) {
+    };
+    if (threadIdx.x < kBinSlots) reset(kWaves, threadIdx.x);
+    __syncthreads();
+    for (uint32_t tile = 0; tile < tiles_per_block; tile++) {
+        const uint64_t start = ((uint64_t)blockIdx.x * tiles_per_block + tile) * kFat;
+        if (start >= n) break;
+        const uint32_t p = (uint32_t)start + threadIdx.x;
+        const uint32_t node = p < n ? node_of[p] : kInactive;
+        if (!__syncthreads_or(node != kInactive)) continue;
+        const uint32_t tile_node = node_of[start];
+        const bool uniform = __syncthreads_and(p >= n || node == tile_node) && tile_node != kInactive;
+        if (!uniform || acc_node != tile_node) {
+            flush();
+            acc_node = uniform ? tile_node : kInactive;
+        }
+        int bin[3] = {-1, -1, -1};
+        uint64_t lo[3], hi[3];
+        if (node != kInactive) {
+            const uint32_t t = idx[p];
+            const double *v = V + 9 * (size_t)t;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const uint64_t ka = key_of(v[k]), kb = key_of(v[3 + k]), kc = key_of(v[6 + k]);
+                uint64_t m = ka < kb ? ka : kb;
+                lo[k] = m < kc ? m : kc;
+                m = ka > kb ? ka : kb;
+                hi[k] = m > kc ? m : kc;
+            }
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const double cmin = value_of(nd.cbox[6 * (size_t)node + a]), cmax = value_of(nd.cbox[6 * (size_t)node + 3 + a]);
+                if (cmin == cmax) continue;                                   // bvh.hpp:252
+                const double scale = kBins / (cmax - cmin);
+                size_t b = static_cast<size_t>((C[3 * (size_t)t + a] - cmin) * scale);
+                if (b > kBins - 1) b = kBins - 1;
+                bin[a] = (int)b;
+            }
+        }
+        auto add_to = [&](int which) {
 #pragma unroll
             for (int a = 0; a < 3; a++) {
                 if (bin[a] < 0) continue;
                 const int s = a * kBins + bin[a];
-                atomicAdd(&s_cnt[wave][s], 1u);
+                atomicAdd(&s_cnt[which][s], 1u);
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
-                    atomicMin(&s_lo[wave][s][k], (unsigned long long)lo[k]);
-                    atomicMax(&s_hi[wave][s][k], (unsigned long long)hi[k]);
+                    atomicMin(&s_lo[which][s][k], (unsigned long long)lo[k]);
+                    atomicMax(&s_hi[which][s][k], (unsigned long long)hi[k]);
                 }
             }
+        };
+        if (uniform) {
+            if (node != kInactive) add_to(kWaves);
+            continue;
         }
-        __syncthreads();
-        if (todo && lane < kBinSlots && s_cnt[wave][lane]) {
-            const size_t w = (size_t)(cur - level_begin) * kBinSlots + lane;
-            atomicAdd(bins.cnt + w, s_cnt[wave][lane]);
-            for (int k = 0; k < 3; k++) {
-                atomicMin((unsigned long long *)bins.lo + 3 * w + k, s_lo[wave][lane][k]);
-                atomicMax((unsigned long long *)bins.hi + 3 * w + k, s_hi[wave][lane][k]);
-            }
+        // runs of this wave, block-uniform number of rounds
+        uint64_t todo = __ballot(node != kInactive);
+        while (__syncthreads_or(todo != 0)) {
+            uint32_t cur = kInactive;
+            if (todo) cur = __shfl(node, __ffsll((unsigned long long)todo) - 1);
+            const bool mine = todo && node == cur;
+            if (lane < kBinSlots) reset(wave, lane);
+            __syncthreads();
+            if (mine) add_to(wave);
+            __syncthreads();
+            if (todo && lane < kBinSlots) send(wave, lane, cur);
+            todo &= ~__ballot(mine);
         }
-        todo &= ~__ballot(mine);
     }
+    flush();
 }
 
 // AABB::area (bvh.hpp:74-78)
@@ -264,7 +337,7 @@ __device__ __forceinline__ double half_area(const double lo[3], const double hi[
 // (bvh.hpp:117-126), one thread per node of the level.
 __global__ void plane_kernel(Nodes nd, Bins bins, uint32_t level_begin, uint32_t level_end) {
     const uint32_t t = level_begin + blockIdx.x * kBlock + threadIdx.x;
-    if (t >= level_end) return;
+    if (t >= level_end || nd.count[t] <= kSmall) return;
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
     double best = inf, best_pos = 0;
     int best_axis = -1;
@@ -428,6 +501,13 @@ __global__ void scan_sums_kernel(uint32_t *__restrict__ sums, uint32_t count) {
     if (threadIdx.x == 0) sums[count] = s_carry;
 }
 
+struct Counters {
+    uint32_t next_id;   // temporary node ids handed out so far
+    uint32_t small;     // entries of the small-subtree list
+    uint32_t big;       // children created so far that stay in the level passes
+    uint32_t deepest;   // deepest level reached inside the small subtrees
+};
+
 struct Prefix {
     const uint32_t *local, *sums;
     __device__ __forceinline__ uint32_t operator()(uint32_t p) const { return sums[p / kScanChunk] + local[p]; }
@@ -436,9 +516,9 @@ struct Prefix {
 // Children of every node that splits (bvh.hpp:141-158); a partition that leaves one side
 // empty makes the node a leaf, but its permutation is still applied (bvh.hpp:139-141).
 __global__ void split_kernel(Nodes nd, Prefix pre, const uint8_t *__restrict__ flag, uint32_t level_begin, uint32_t level_end,
-                             uint32_t *__restrict__ next_id) {
+                             Counters *__restrict__ counters, uint2 *__restrict__ small_list, uint32_t level) {
     const uint32_t t = level_begin + blockIdx.x * kBlock + threadIdx.x;
-    if (t >= level_end || nd.axis[t] < 0) return;
+    if (t >= level_end || nd.count[t] <= kSmall || nd.axis[t] < 0) return;
     const uint32_t f0 = nd.first[t], m = nd.count[t];
     const uint32_t e0 = pre(f0);
     const uint32_t nl = pre(f0 + m - 1) + flag[f0 + m - 1] - e0;
@@ -447,10 +527,17 @@ __global__ void split_kernel(Nodes nd, Prefix pre, const uint8_t *__restrict__ f
     nd.nleft[t] = nl;
     nd.kstar[t] = ks;
     if (nl == 0 || nl == m) return;
-    const uint32_t c = atomicAdd(next_id, 2u);
+    const uint32_t c = atomicAdd(&counters->next_id, 2u);
     nd.child[t] = c;
     init_node(nd, c, f0, nl, t, ((nd.link[t] >> 1) + 1) << 1);
     init_node(nd, c + 1, f0 + nl, m - nl, t, 1u);
+    const uint32_t sizes[2] = {nl, m - nl};
+    uint32_t big = 0;
+    for (int k = 0; k < 2; k++) {
+        if (sizes[k] <= kSmall) small_list[atomicAdd(&counters->small, 1u)] = make_uint2(c + k, level + 1);
+        else big++;
+    }
+    if (big) atomicAdd(&counters->big, big);
 }
 
 // Positions (relative to the node) of the k-th right element of A and of the k-th left
@@ -496,13 +583,315 @@ __global__ void permute_kernel(const uint32_t *__restrict__ idx, const uint32_t 
     }
     idx_out[f0 + dest] = idx[p];
     const uint32_t c = nd.child[t];
-    node_out[f0 + dest] = c ? (dest < nl ? c : c + 1) : kInactive;
+    uint32_t to = kInactive;
+    if (c) {
+        to = dest < nl ? c : c + 1;
+        if ((dest < nl ? nl : m - nl) <= kSmall) to = kInactive;
+    }
+    node_out[f0 + dest] = to;
+}
+
+
+// ---- one wave builds a whole small subtree -------------------------------------------
+
+__device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int m) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, m), hi = __shfl_xor((uint32_t)(v >> 32), m);
+    return ((uint64_t)hi << 32) | lo;
+}
+template <bool IS_MIN>
+__device__ __forceinline__ uint64_t wave_reduce64(uint64_t v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const uint64_t o = shfl_xor64(v, m);
+        v = IS_MIN ? (o < v ? o : v) : (o > v ? o : v);
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max32(uint32_t v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const uint32_t o = __shfl_xor(v, m);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v |= shfl_xor64(v, m);
+    return v;
+}
+__device__ __forceinline__ double shfl_f64(double v, int src) {
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = __shfl((uint32_t)b, src), hi = __shfl((uint32_t)(b >> 32), src);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int src) {
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src), hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t low_mask(uint32_t k) { return k >= 64 ? ~0ull : ((1ull << k) - 1); }
+// Position of the k-th set bit (k >= 1, counted from bit 0) of a mask that has one.
+__device__ __forceinline__ uint32_t select_bit(uint64_t mask, uint32_t k) {
+    uint32_t pos = 0;
+#pragma unroll
+    for (int step = 32; step; step >>= 1)
+        if ((uint32_t)__popcll(mask & low_mask(pos + step)) < k) pos += step;
+    return pos;
+}
+// LDS traffic of one wave is executed in order; this keeps the compiler from moving
+// accesses across the point where other lanes' writes are consumed.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// subdivide (bvh.hpp:117-162) for every node below a small root, by one wave: lane = one
+// triangle of the root, which keeps its data in registers and only changes its position
+// `pos` inside the root's range when a partition moves it.  Pending nodes are kept in a
+// stack spread over the lanes' registers.  Node ids come from a block of 2m-2 ids reserved
+// for the root; ids left over are marked unused.
+__global__ __launch_bounds__(kBlock) void subtree_kernel(const double *__restrict__ V, const double *__restrict__ C,
+                                                         uint32_t *__restrict__ idx, const uint2 *__restrict__ small_list,
+                                                         const uint32_t *__restrict__ need_local,
+                                                         const uint32_t *__restrict__ need_sums, uint32_t n_small,
+                                                         uint32_t id_base, Nodes nd, Counters *__restrict__ counters) {
+    __shared__ unsigned long long s_lo[kBlock / 64][kBinSlots][3], s_hi[kBlock / 64][kBinSlots][3];
+    __shared__ uint32_t s_cnt[kBlock / 64][kBinSlots];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t w = blockIdx.x * (kBlock / 64) + wave;
+    if (w >= n_small) return;                       // whole waves leave; no block barrier below
+    const uint2 entry = small_list[w];
+    const uint32_t root = entry.x;
+    const uint32_t f0 = nd.first[root], m = nd.count[root];
+    uint32_t next_free = id_base + need_sums[w / kScanChunk] + need_local[w];
+    const uint32_t id_end = next_free + 2 * m - 2;
+    const bool active = (uint32_t)lane < m;
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+
+    uint32_t tri = 0, pos = lane;
+    double c[3] = {0, 0, 0};
+    uint64_t lo[3], hi[3];
+    uint32_t zinfo[3] = {0, 0, 0};     // ((index of the last zero vertex + 1) << 1) | sign, 0 = none
+#pragma unroll
+    for (int k = 0; k < 3; k++) { lo[k] = kKeyMinInit; hi[k] = kKeyMaxInit; }
+    if (active) {
+        tri = idx[f0 + lane];
+        const double *v = V + 9 * (size_t)tri;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const double a = v[k], b = v[3 + k], cc = v[6 + k];
+            const uint64_t ka = key_of(a), kb = key_of(b), kc = key_of(cc);
+            uint64_t t = ka < kb ? ka : kb;
+            lo[k] = t < kc ? t : kc;
+            t = ka > kb ? ka : kb;
+            hi[k] = t > kc ? t : kc;
+            if (a == 0.0) zinfo[k] = (1u << 1) | (uint32_t)(ka >> 63);
+            if (b == 0.0) zinfo[k] = (2u << 1) | (uint32_t)(kb >> 63);
+            if (cc == 0.0) zinfo[k] = (3u << 1) | (uint32_t)(kc >> 63);
+            c[k] = C[3 * (size_t)tri + k];
+        }
+    }
+
+    // pending nodes: entry e lives in lane e
+    uint32_t st_range = 0, st_id = 0, st_run = 0;
+    int sp = 0;
+    if (lane == 0) { st_range = 0u | (m << 8) | (entry.y << 16); st_id = root; st_run = nd.link[root] >> 1; }
+    sp = 1;
+    uint32_t deepest = entry.y;
+
+    while (sp > 0) {
+        sp = __builtin_amdgcn_readfirstlane(sp - 1);
+        const uint32_t range = __builtin_amdgcn_readlane(st_range, sp);
+        const uint32_t id = __builtin_amdgcn_readlane(st_id, sp);
+        const uint32_t run = __builtin_amdgcn_readlane(st_run, sp);
+        const uint32_t a = range & 0xff, b = (range >> 8) & 0xff, lev = range >> 16;
+        const uint32_t cnt = b - a;
+        deepest = lev > deepest ? lev : deepest;
+        const bool member = active && pos >= a && pos < b;
+
+        // updateNodeBounds (bvh.hpp:100-115) and the centroid bounds of bvh.hpp:242-250.
+        // Few members: read them lane by lane into uniform values; many: butterfly reductions.
+        uint64_t box[6], zero[3], cbox_k[6];
+        if (cnt <= kSerialMembers) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                box[k] = cbox_k[k] = kKeyMinInit;
+                box[3 + k] = cbox_k[3 + k] = kKeyMaxInit;
+                zero[k] = 0;
+            }
+            uint64_t todo = __ballot(member);
+            while (todo) {
+                const int src = __ffsll((unsigned long long)todo) - 1;
+                todo &= todo - 1;
+                const uint32_t p_src = __builtin_amdgcn_readlane(pos, src);
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const uint64_t l = readlane64(lo[k], src), h = readlane64(hi[k], src);
+                    const uint64_t kc = key_of(__longlong_as_double((long long)readlane64((uint64_t)__double_as_longlong(c[k]), src)));
+                    const uint32_t zi = __builtin_amdgcn_readlane(zinfo[k], src);
+                    box[k] = l < box[k] ? l : box[k];
+                    box[3 + k] = h > box[3 + k] ? h : box[3 + k];
+                    cbox_k[k] = kc < cbox_k[k] ? kc : cbox_k[k];
+                    cbox_k[3 + k] = kc > cbox_k[3 + k] ? kc : cbox_k[3 + k];
+                    const uint64_t z = zi ? ((p_src * 3 + (zi >> 1)) << 1) | (zi & 1) : 0u;
+                    zero[k] = z > zero[k] ? z : zero[k];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                box[k] = wave_reduce64<true>(member ? lo[k] : kKeyMinInit);
+                box[3 + k] = wave_reduce64<false>(member ? hi[k] : kKeyMaxInit);
+                const uint32_t z = (member && zinfo[k]) ? ((pos * 3 + (zinfo[k] >> 1)) << 1) | (zinfo[k] & 1) : 0u;
+                zero[k] = wave_max32(z);
+                const uint64_t kc = key_of(c[k]);
+                cbox_k[k] = wave_reduce64<true>(member ? kc : kKeyMinInit);
+                cbox_k[3 + k] = wave_reduce64<false>(member ? kc : kKeyMaxInit);
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) nd.box[6 * (size_t)id + k] = box[k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) nd.zero[3 * (size_t)id + k] = zero[k];
+        }
+
+        // findBestSplitPlane (bvh.hpp:236-305)
+        double best = inf, best_pos = 0;
+        int best_axis = -1;
+        if (cnt >= 2) {
+            double cmin[3], cmax[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { cmin[k] = value_of(cbox_k[k]); cmax[k] = value_of(cbox_k[3 + k]); }
+            if (lane < kBinSlots) {
+                s_cnt[wave][lane] = 0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) { s_lo[wave][lane][k] = kKeyMinInit; s_hi[wave][lane][k] = kKeyMaxInit; }
+            }
+            wave_sync();
+            if (member) {
+#pragma unroll
+                for (int ax = 0; ax < 3; ax++) {
+                    if (cmin[ax] == cmax[ax]) continue;
+                    const double scale = kBins / (cmax[ax] - cmin[ax]);
+                    size_t bb = static_cast<size_t>((c[ax] - cmin[ax]) * scale);
+                    if (bb > kBins - 1) bb = kBins - 1;
+                    const int s = ax * kBins + (int)bb;
+                    atomicAdd(&s_cnt[wave][s], 1u);
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        atomicMin(&s_lo[wave][s][k], (unsigned long long)lo[k]);
+                        atomicMax(&s_hi[wave][s][k], (unsigned long long)hi[k]);
+                    }
+                }
+            }
+            wave_sync();
+            // lanes 0..20: one candidate plane each (axis-major, as the reference scans them)
+            const int ax = lane / (kBins - 1), plane = lane % (kBins - 1);
+            double cost = inf, cand_pos = 0;
+            if (lane < 3 * (kBins - 1)) {
+                const double lo_c = ax == 0 ? cmin[0] : ax == 1 ? cmin[1] : cmin[2];
+                const double hi_c = ax == 0 ? cmax[0] : ax == 1 ? cmax[1] : cmax[2];
+                if (lo_c != hi_c) {
+                    double llo[3] = {inf, inf, inf}, lhi[3] = {-inf, -inf, -inf};
+                    double rlo[3] = {inf, inf, inf}, rhi[3] = {-inf, -inf, -inf};
+                    int lcount = 0, rcount = 0;
+                    for (int bb = 0; bb < kBins; bb++) {
+                        const int s = ax * kBins + bb;
+                        const int bc = (int)s_cnt[wave][s];
+                        if (!bc) continue;
+                        const bool left = bb <= plane;
+                        if (left) lcount += bc; else rcount += bc;
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            const double bl = value_of(s_lo[wave][s][k]), bh = value_of(s_hi[wave][s][k]);
+                            if (left) { llo[k] = llo[k] < bl ? llo[k] : bl; lhi[k] = lhi[k] > bh ? lhi[k] : bh; }
+                            else { rlo[k] = rlo[k] < bl ? rlo[k] : bl; rhi[k] = rhi[k] > bh ? rhi[k] : bh; }
+                        }
+                    }
+                    const double v = lcount * half_area(llo, lhi) + rcount * half_area(rlo, rhi);
+                    if (v < inf) cost = v;               // NaN and +inf never win (bvh.hpp:297)
+                    const double width = (hi_c - lo_c) / kBins;
+                    cand_pos = lo_c + width * static_cast<double>(plane + 1);
+                }
+            }
+            // smallest cost; on a tie the candidate the sequential scan meets first
+            double bc = cost;
+            int bl = lane;
+#pragma unroll
+            for (int mm = 1; mm < 64; mm <<= 1) {
+                const double oc = __longlong_as_double((long long)shfl_xor64((uint64_t)__double_as_longlong(bc), mm));   // NOLINT
+                const int ol = __shfl_xor(bl, mm);
+                if (oc < bc || (oc == bc && ol < bl)) { bc = oc; bl = ol; }
+            }
+            if (bc < inf) {
+                best = bc;
+                best_axis = bl / (kBins - 1);
+                best_pos = shfl_f64(cand_pos, bl);
+            }
+            wave_sync();
+        }
+        double blo[3], bhi[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { blo[k] = value_of(box[k]); bhi[k] = value_of(box[3 + k]); }
+        const double parent_cost = static_cast<double>(cnt) * half_area(blo, bhi);      // bvh.hpp:80-82
+        if (best >= parent_cost) best_axis = -1;
+
+        uint32_t child = 0;
+        if (best_axis >= 0) {
+            // partition (bvh.hpp:128-140) as a permutation of positions
+            const double mine = best_axis == 0 ? c[0] : best_axis == 1 ? c[1] : c[2];
+            const bool f = member && mine < best_pos;
+            const uint32_t rel = pos - a;
+            const uint64_t F = wave_or64(f ? 1ull << rel : 0ull);
+            const uint32_t nl = (uint32_t)__popcll(F);
+            const uint64_t RA = ~F & low_mask(nl), LB = F & ~low_mask(nl);
+            const uint32_t ks = (uint32_t)__popcll(RA);
+            if (member) {
+                uint32_t dest;
+                if (rel < nl) {
+                    if (f) dest = rel;
+                    else {
+                        const uint32_t k = (uint32_t)__popcll(RA & low_mask(rel)) + 1;
+                        dest = (k == 1 ? cnt : select_bit(LB, ks - (k - 1) + 1)) - 1;   // (k-1)-th left of B from the back
+                    }
+                } else {
+                    if (f) dest = select_bit(RA, (uint32_t)__popcll(LB >> rel));
+                    else if (rel == nl) dest = (ks == 0 ? cnt : select_bit(LB, 1)) - 1;   // ks-th from the back = lowest
+                    else dest = rel - 1;
+                }
+                pos = a + dest;
+            }
+            if (nl != 0 && nl != cnt) {
+                child = next_free;
+                next_free += 2;
+                if (lane == 0) {
+                    nd.first[child] = f0 + a; nd.count[child] = nl; nd.parent[child] = id; nd.link[child] = (run + 1) << 1;
+                    nd.first[child + 1] = f0 + a + nl; nd.count[child + 1] = cnt - nl; nd.parent[child + 1] = id; nd.link[child + 1] = 1u;
+                }
+                if (lane == sp) { st_range = (a + nl) | (b << 8) | ((lev + 1) << 16); st_id = child + 1; st_run = 0; }
+                if (lane == sp + 1) { st_range = a | ((a + nl) << 8) | ((lev + 1) << 16); st_id = child; st_run = run + 1; }
+                sp += 2;
+            }
+        }
+        if (lane == 0) nd.child[id] = child;
+    }
+    if (active) idx[f0 + pos] = tri;
+    for (uint32_t t = next_free + lane; t < id_end; t += 64) nd.parent[t] = kInactive;
+    if (lane == 0) atomicMax(&counters->deepest, deepest);
+}
+
+// Ids a small root may need: 2m-2.
+__global__ void subtree_need_kernel(const uint2 *__restrict__ small_list, uint32_t n_small, Nodes nd, uint32_t *__restrict__ need) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n_small) need[i] = 2 * nd.count[small_list[i].x] - 2;
 }
 
 // Number of inner nodes that start at each position.
 __global__ void inner_count_kernel(Nodes nd, uint32_t n_nodes, uint32_t *__restrict__ starts) {
     const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-    if (t < n_nodes && nd.child[t]) atomicAdd(starts + nd.first[t], 1u);
+    if (t < n_nodes && nd.parent[t] != kInactive && nd.child[t]) atomicAdd(starts + nd.first[t], 1u);
 }
 
 // Stored bound of a node: the reduced value, with the sign of a zero taken from the
@@ -516,7 +905,7 @@ __device__ __forceinline__ double zero_sign(double v, uint64_t tracker) {
 // Writes the reference's node array: pre-order pair numbering.
 __global__ void emit_kernel(Nodes nd, uint32_t n_nodes, Prefix pre, rtx_bvh_node *__restrict__ out) {
     const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-    if (t >= n_nodes) return;
+    if (t >= n_nodes || nd.parent[t] == kInactive) return;
     uint64_t where = 0;
     if (t != 0) {
         const uint32_t par = nd.parent[t];
@@ -571,12 +960,17 @@ int build_bvh_device(const double *vertices, uint64_t n64, rtx_bvh_node *nodes_o
     if (n64 == 0) { *err = "cannot build a BVH over zero triangles"; return RTX_ERR_INVALID; }
     if (n64 >= (1ull << 28)) { *err = "more than 2^28 triangles"; return RTX_ERR_UNSUPPORTED; }
     const uint32_t n = (uint32_t)n64;
-    const uint32_t cap = 2 * n - 1;
+    // Nodes of the level passes: those with more than kSmall triangles (their leaves have
+    // disjoint ranges, so fewer than 2n/kSmall of them) and their small children.
+    const uint32_t top_cap = n / 8 + 1024;
+    const uint32_t cap = top_cap + 2 * n;            // + 2m-2 reserved ids per small root
     const uint32_t chunks = blocks_for(n, kScanChunk);
     DeviceBuffers buf;
     double *V, *C;
-    uint32_t *idx[2], *node_of[2], *local, *sums, *holes, *fills, *next_id, *starts;
+    uint32_t *idx[2], *node_of[2], *local, *sums, *holes, *fills, *starts;
     uint8_t *flag;
+    uint2 *small_list;
+    Counters *counters;
     Nodes nd;
     HIP_TRY_B(buf.get(&V, 9 * (size_t)n));
     HIP_TRY_B(buf.get(&C, 3 * (size_t)n));
@@ -586,16 +980,17 @@ int build_bvh_device(const double *vertices, uint64_t n64, rtx_bvh_node *nodes_o
     HIP_TRY_B(buf.get(&holes, n));
     HIP_TRY_B(buf.get(&fills, n));
     HIP_TRY_B(buf.get(&flag, n));
-    HIP_TRY_B(buf.get(&next_id, 1));
+    HIP_TRY_B(buf.get(&counters, 1));
+    HIP_TRY_B(buf.get(&small_list, n));
     HIP_TRY_B(buf.get(&starts, n));
     HIP_TRY_B(buf.get(&nd.first, cap)); HIP_TRY_B(buf.get(&nd.count, cap)); HIP_TRY_B(buf.get(&nd.parent, cap));
-    HIP_TRY_B(buf.get(&nd.link, cap)); HIP_TRY_B(buf.get(&nd.child, cap)); HIP_TRY_B(buf.get(&nd.axis, cap));
-    HIP_TRY_B(buf.get(&nd.pos, cap)); HIP_TRY_B(buf.get(&nd.nleft, cap)); HIP_TRY_B(buf.get(&nd.kstar, cap));
-    HIP_TRY_B(buf.get(&nd.box, 6 * (size_t)cap)); HIP_TRY_B(buf.get(&nd.cbox, 6 * (size_t)cap));
-    HIP_TRY_B(buf.get(&nd.zero, 3 * (size_t)cap));
+    HIP_TRY_B(buf.get(&nd.link, cap)); HIP_TRY_B(buf.get(&nd.child, cap));
+    HIP_TRY_B(buf.get(&nd.box, 6 * (size_t)cap)); HIP_TRY_B(buf.get(&nd.zero, 3 * (size_t)cap));
+    HIP_TRY_B(buf.get(&nd.axis, top_cap)); HIP_TRY_B(buf.get(&nd.pos, top_cap)); HIP_TRY_B(buf.get(&nd.nleft, top_cap));
+    HIP_TRY_B(buf.get(&nd.kstar, top_cap)); HIP_TRY_B(buf.get(&nd.cbox, 6 * (size_t)top_cap));
     rtx_bvh_node *d_out;
     uint64_t *d_indices;
-    HIP_TRY_B(buf.get(&d_out, cap));
+    HIP_TRY_B(buf.get(&d_out, 2 * (size_t)n - 1));
     HIP_TRY_B(buf.get(&d_indices, n));
 
     hipStream_t stream = nullptr;
@@ -607,21 +1002,31 @@ int build_bvh_device(const double *vertices, uint64_t n64, rtx_bvh_node *nodes_o
     HIP_TRY_B(hipEventRecord(ev0, stream));
 
     const uint32_t pos_blocks = blocks_for(n);
-    uint32_t one = 1;
-    HIP_TRY_B(hipMemcpyAsync(next_id, &one, sizeof one, hipMemcpyHostToDevice, stream));
+    // about one fat block per CU
+    const uint32_t tiles = blocks_for(n, kFat);
+    const uint32_t tiles_per_block = std::min<uint32_t>(std::max<uint32_t>(tiles / 256, 1), 16);
+    const uint32_t fat_blocks = blocks_for(tiles, tiles_per_block);
+    Counters host_counters{1, 0, 0, 0};
+    const bool root_is_small = n <= kSmall;
+    if (root_is_small) {
+        host_counters.small = 1;
+        const uint2 root_entry = make_uint2(0, 0);
+        HIP_TRY_B(hipMemcpyAsync(small_list, &root_entry, sizeof root_entry, hipMemcpyHostToDevice, stream));
+    }
+    HIP_TRY_B(hipMemcpyAsync(counters, &host_counters, sizeof host_counters, hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(centroid_kernel, dim3(pos_blocks), dim3(kBlock), 0, stream, V, C, idx[0], node_of[0], n, nd);
-    hipLaunchKernelGGL(bounds_kernel, dim3(pos_blocks), dim3(kBlock), 0, stream, V, C, idx[0], node_of[0], n, nd);
 
     Bins bins{nullptr, nullptr, nullptr};
     uint64_t bins_width = 0;
     const Prefix pre{local, sums};
     uint32_t level_begin = 0, level_end = 1;
     int cur = 0, depth = 0;
-    for (;; depth++) {
+    for (uint32_t level = 0; !root_is_small; level++) {
+        depth = (int)level;
+        hipLaunchKernelGGL(bounds_kernel, dim3(fat_blocks), dim3(kFat), 0, stream, V, C, idx[cur], node_of[cur], n, nd, tiles_per_block);
         const uint32_t width = level_end - level_begin;
         if (width > bins_width) {
-            bins_width = std::max<uint64_t>(width, 2 * bins_width);
-            bins_width = std::min<uint64_t>(bins_width, cap);
+            bins_width = std::min<uint64_t>(std::max<uint64_t>(width, 2 * bins_width), top_cap);
             HIP_TRY_B(buf.get(&bins.lo, bins_width * kBinSlots * 3));
             HIP_TRY_B(buf.get(&bins.hi, bins_width * kBinSlots * 3));
             HIP_TRY_B(buf.get(&bins.cnt, bins_width * kBinSlots));
@@ -630,33 +1035,56 @@ int build_bvh_device(const double *vertices, uint64_t n64, rtx_bvh_node *nodes_o
         HIP_TRY_B(hipMemsetAsync(bins.hi, 0x00, (size_t)width * kBinSlots * 3 * sizeof(uint64_t), stream));
         HIP_TRY_B(hipMemsetAsync(bins.cnt, 0x00, (size_t)width * kBinSlots * sizeof(uint32_t), stream));
         const uint32_t node_blocks = blocks_for(width);
-        hipLaunchKernelGGL(bin_kernel, dim3(pos_blocks), dim3(kBlock), 0, stream, V, C, idx[cur], node_of[cur], n, nd, bins, level_begin);
+        hipLaunchKernelGGL(bin_kernel, dim3(fat_blocks), dim3(kFat), 0, stream, V, C, idx[cur], node_of[cur], n, nd, bins, level_begin,
+                           tiles_per_block);
         hipLaunchKernelGGL(plane_kernel, dim3(node_blocks), dim3(kBlock), 0, stream, nd, bins, level_begin, level_end);
         hipLaunchKernelGGL(flag_kernel, dim3(chunks), dim3(kBlock), 0, stream, C, idx[cur], node_of[cur], n, nd, flag, local, sums);
         hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, stream, sums, chunks);
-        hipLaunchKernelGGL(split_kernel, dim3(node_blocks), dim3(kBlock), 0, stream, nd, pre, flag, level_begin, level_end, next_id);
+        hipLaunchKernelGGL(split_kernel, dim3(node_blocks), dim3(kBlock), 0, stream, nd, pre, flag, level_begin, level_end, counters,
+                           small_list, level);
         hipLaunchKernelGGL(holes_kernel, dim3(pos_blocks), dim3(kBlock), 0, stream, node_of[cur], n, nd, pre, flag, holes, fills);
         hipLaunchKernelGGL(permute_kernel, dim3(pos_blocks), dim3(kBlock), 0, stream, idx[cur], node_of[cur], n, nd, pre, flag, holes,
                            fills, idx[cur ^ 1], node_of[cur ^ 1]);
         cur ^= 1;
-        uint32_t next = 0;
-        HIP_TRY_B(hipMemcpyAsync(&next, next_id, sizeof next, hipMemcpyDeviceToHost, stream));
+        const uint32_t big_before = host_counters.big;
+        HIP_TRY_B(hipMemcpyAsync(&host_counters, counters, sizeof host_counters, hipMemcpyDeviceToHost, stream));
         HIP_TRY_B(hipStreamSynchronize(stream));
-        if (next > cap) { *err = "BVH build: node counter overran its bound"; return RTX_ERR_DEVICE; }
-        if (next == level_end) break;
+        if (host_counters.next_id > top_cap) { *err = "BVH build: more level nodes than their bound"; return RTX_ERR_DEVICE; }
+        if (host_counters.next_id != level_end) depth = (int)level + 1;
+        if (host_counters.big == big_before) break;
         level_begin = level_end;
-        level_end = next;
-        hipLaunchKernelGGL(bounds_kernel, dim3(pos_blocks), dim3(kBlock), 0, stream, V, C, idx[cur], node_of[cur], n, nd);
+        level_end = host_counters.next_id;
     }
-    const uint32_t n_nodes = level_end;
+    uint32_t total_ids = host_counters.next_id;
+    const uint32_t n_small = host_counters.small;
+    if (n_small) {
+        const uint32_t small_chunks = blocks_for(n_small, kScanChunk);
+        hipLaunchKernelGGL(subtree_need_kernel, dim3(blocks_for(n_small)), dim3(kBlock), 0, stream, small_list, n_small, nd, local);
+        hipLaunchKernelGGL(local_scan_kernel, dim3(small_chunks), dim3(kBlock), 0, stream, local, n_small, sums);
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, stream, sums, small_chunks);
+        hipLaunchKernelGGL(subtree_kernel, dim3(blocks_for(n_small, kBlock / 64)), dim3(kBlock), 0, stream, V, C, idx[cur], small_list,
+                           local, sums, n_small, host_counters.next_id, nd, counters);
+        uint32_t reserved = 0;
+        HIP_TRY_B(hipMemcpyAsync(&reserved, sums + small_chunks, sizeof reserved, hipMemcpyDeviceToHost, stream));
+        HIP_TRY_B(hipMemcpyAsync(&host_counters, counters, sizeof host_counters, hipMemcpyDeviceToHost, stream));
+        HIP_TRY_B(hipStreamSynchronize(stream));
+        total_ids += reserved;
+        if (total_ids > cap) { *err = "BVH build: node ids overran their bound"; return RTX_ERR_DEVICE; }
+        depth = std::max<int>(depth, (int)host_counters.deepest);
+    }
     HIP_TRY_B(hipMemsetAsync(starts, 0, (size_t)n * sizeof(uint32_t), stream));
-    hipLaunchKernelGGL(inner_count_kernel, dim3(blocks_for(n_nodes)), dim3(kBlock), 0, stream, nd, n_nodes, starts);
+    hipLaunchKernelGGL(inner_count_kernel, dim3(blocks_for(total_ids)), dim3(kBlock), 0, stream, nd, total_ids, starts);
     hipLaunchKernelGGL(local_scan_kernel, dim3(chunks), dim3(kBlock), 0, stream, starts, n, sums);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, stream, sums, chunks);
-    hipLaunchKernelGGL(emit_kernel, dim3(blocks_for(n_nodes)), dim3(kBlock), 0, stream, nd, n_nodes, Prefix{starts, sums}, d_out);
+    hipLaunchKernelGGL(emit_kernel, dim3(blocks_for(total_ids)), dim3(kBlock), 0, stream, nd, total_ids, Prefix{starts, sums}, d_out);
     hipLaunchKernelGGL(widen_kernel, dim3(pos_blocks), dim3(kBlock), 0, stream, idx[cur], d_indices, n);
+    uint32_t inner = 0;
+    HIP_TRY_B(hipMemcpyAsync(&inner, sums + chunks, sizeof inner, hipMemcpyDeviceToHost, stream));
     HIP_TRY_B(hipEventRecord(ev1, stream));
+    HIP_TRY_B(hipStreamSynchronize(stream));
     HIP_TRY_B(hipGetLastError());
+    const uint64_t n_nodes = 1 + 2 * (uint64_t)inner;
+    if (n_nodes > 2 * (uint64_t)n - 1) { *err = "BVH build: inconsistent node count"; return RTX_ERR_DEVICE; }
     HIP_TRY_B(hipMemcpy(nodes_out, d_out, (size_t)n_nodes * sizeof(rtx_bvh_node), hipMemcpyDeviceToHost));
     HIP_TRY_B(hipMemcpy(indices_out, d_indices, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
     float ms = 0;
