@@ -594,40 +594,68 @@ __global__ void permute_kernel(const uint32_t *__restrict__ idx, const uint32_t 
 
 // ---- one wave builds a whole small subtree -------------------------------------------
 
-__device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int m) {
-    const uint32_t lo = __shfl_xor((uint32_t)v, m), hi = __shfl_xor((uint32_t)(v >> 32), m);
+// Wave reductions without trips through memory: four DPP exchanges inside rows of 16 lanes
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror), one ds_swizzle
+// across the rows of a half wave (lane ^ 16) and two readlanes across the halves.  The
+// result is uniform.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ uint64_t dpp64(uint64_t v) {
+    return ((uint64_t)dpp32<CTRL>((uint32_t)(v >> 32)) << 32) | dpp32<CTRL>((uint32_t)v);
+}
+__device__ __forceinline__ uint32_t swz16_32(uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F); }
+__device__ __forceinline__ uint64_t swz16_64(uint64_t v) {
+    return ((uint64_t)swz16_32((uint32_t)(v >> 32)) << 32) | swz16_32((uint32_t)v);
+}
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int src) {
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src), hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src);
     return ((uint64_t)hi << 32) | lo;
 }
 template <bool IS_MIN>
+__device__ __forceinline__ uint64_t pick64(uint64_t a, uint64_t b) { return IS_MIN ? (b < a ? b : a) : (b > a ? b : a); }
+template <bool IS_MIN>
 __device__ __forceinline__ uint64_t wave_reduce64(uint64_t v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const uint64_t o = shfl_xor64(v, m);
-        v = IS_MIN ? (o < v ? o : v) : (o > v ? o : v);
-    }
-    return v;
+    v = pick64<IS_MIN>(v, dpp64<0xB1>(v));
+    v = pick64<IS_MIN>(v, dpp64<0x4E>(v));
+    v = pick64<IS_MIN>(v, dpp64<0x141>(v));
+    v = pick64<IS_MIN>(v, dpp64<0x140>(v));
+    v = pick64<IS_MIN>(v, swz16_64(v));
+    return pick64<IS_MIN>(readlane64(v, 0), readlane64(v, 32));
 }
 __device__ __forceinline__ uint32_t wave_max32(uint32_t v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const uint32_t o = __shfl_xor(v, m);
-        v = o > v ? o : v;
-    }
-    return v;
+    uint32_t o;
+    o = dpp32<0xB1>(v); v = o > v ? o : v;
+    o = dpp32<0x4E>(v); v = o > v ? o : v;
+    o = dpp32<0x141>(v); v = o > v ? o : v;
+    o = dpp32<0x140>(v); v = o > v ? o : v;
+    o = swz16_32(v); v = o > v ? o : v;
+    const uint32_t x = __builtin_amdgcn_readlane(v, 0), y = __builtin_amdgcn_readlane(v, 32);
+    return x > y ? x : y;
 }
-__device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v |= shfl_xor64(v, m);
-    return v;
+// Smallest cost over the wave; on equal costs the smallest tag.
+__device__ __forceinline__ void wave_argmin(double &cost, int &tag) {
+    auto step = [&](uint64_t oc_bits, uint32_t ot) {
+        const double oc = __longlong_as_double((long long)oc_bits);
+        if (oc < cost || (oc == cost && (int)ot < tag)) { cost = oc; tag = (int)ot; }
+    };
+    step(dpp64<0xB1>((uint64_t)__double_as_longlong(cost)), dpp32<0xB1>((uint32_t)tag));
+    step(dpp64<0x4E>((uint64_t)__double_as_longlong(cost)), dpp32<0x4E>((uint32_t)tag));
+    step(dpp64<0x141>((uint64_t)__double_as_longlong(cost)), dpp32<0x141>((uint32_t)tag));
+    step(dpp64<0x140>((uint64_t)__double_as_longlong(cost)), dpp32<0x140>((uint32_t)tag));
+    step(swz16_64((uint64_t)__double_as_longlong(cost)), swz16_32((uint32_t)tag));
+    const uint64_t c0 = readlane64((uint64_t)__double_as_longlong(cost), 0), c1 = readlane64((uint64_t)__double_as_longlong(cost), 32);
+    const uint32_t t0 = __builtin_amdgcn_readlane((uint32_t)tag, 0), t1 = __builtin_amdgcn_readlane((uint32_t)tag, 32);
+    cost = __longlong_as_double((long long)c0);
+    tag = (int)t0;
+    step(c1, t1);
 }
 __device__ __forceinline__ double shfl_f64(double v, int src) {
     const uint64_t b = (uint64_t)__double_as_longlong(v);
     const uint32_t lo = __shfl((uint32_t)b, src), hi = __shfl((uint32_t)(b >> 32), src);
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
-}
-__device__ __forceinline__ uint64_t readlane64(uint64_t v, int src) {
-    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src), hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src);
-    return ((uint64_t)hi << 32) | lo;
 }
 __device__ __forceinline__ uint64_t low_mask(uint32_t k) { return k >= 64 ? ~0ull : ((1ull << k) - 1); }
 // Position of the k-th set bit (k >= 1, counted from bit 0) of a mask that has one.
@@ -819,12 +847,7 @@ __global__ __launch_bounds__(kBlock) void subtree_kernel(const double *__restric
             // smallest cost; on a tie the candidate the sequential scan meets first
             double bc = cost;
             int bl = lane;
-#pragma unroll
-            for (int mm = 1; mm < 64; mm <<= 1) {
-                const double oc = __longlong_as_double((long long)shfl_xor64((uint64_t)__double_as_longlong(bc), mm));   // NOLINT
-                const int ol = __shfl_xor(bl, mm);
-                if (oc < bc || (oc == bc && ol < bl)) { bc = oc; bl = ol; }
-            }
+            wave_argmin(bc, bl);
             if (bc < inf) {
                 best = bc;
                 best_axis = bl / (kBins - 1);
@@ -844,7 +867,8 @@ __global__ __launch_bounds__(kBlock) void subtree_kernel(const double *__restric
             const double mine = best_axis == 0 ? c[0] : best_axis == 1 ? c[1] : c[2];
             const bool f = member && mine < best_pos;
             const uint32_t rel = pos - a;
-            const uint64_t F = wave_or64(f ? 1ull << rel : 0ull);
+            // lane L receives the flag of the triangle at position L
+            const uint64_t F = __ballot(__builtin_amdgcn_ds_permute((int)(pos << 2), f ? 1 : 0) != 0) >> a;
             const uint32_t nl = (uint32_t)__popcll(F);
             const uint64_t RA = ~F & low_mask(nl), LB = F & ~low_mask(nl);
             const uint32_t ks = (uint32_t)__popcll(RA);
@@ -1002,10 +1026,7 @@ int build_bvh_device(const double *vertices, uint64_t n64, rtx_bvh_node *nodes_o
     HIP_TRY_B(hipEventRecord(ev0, stream));
 
     const uint32_t pos_blocks = blocks_for(n);
-    // about one fat block per CU
     const uint32_t tiles = blocks_for(n, kFat);
-    const uint32_t tiles_per_block = std::min<uint32_t>(std::max<uint32_t>(tiles / 256, 1), 16);
-    const uint32_t fat_blocks = blocks_for(tiles, tiles_per_block);
     Counters host_counters{1, 0, 0, 0};
     const bool root_is_small = n <= kSmall;
     if (root_is_small) {
@@ -1023,6 +1044,11 @@ int build_bvh_device(const double *vertices, uint64_t n64, rtx_bvh_node *nodes_o
     int cur = 0, depth = 0;
     for (uint32_t level = 0; !root_is_small; level++) {
         depth = (int)level;
+        // While a level has only a few nodes every block's atomics meet at the same few
+        // addresses: then a block walks several tiles and sends one set per node.  Later
+        // one tile per block keeps more loads in flight.
+        const uint32_t tiles_per_block = (level_end - level_begin) < 8 ? std::min<uint32_t>(std::max<uint32_t>(tiles / 256, 1), 8) : 1;
+        const uint32_t fat_blocks = blocks_for(tiles, tiles_per_block);
         hipLaunchKernelGGL(bounds_kernel, dim3(fat_blocks), dim3(kFat), 0, stream, V, C, idx[cur], node_of[cur], n, nd, tiles_per_block);
         const uint32_t width = level_end - level_begin;
         if (width > bins_width) {
