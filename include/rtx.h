@@ -35,6 +35,11 @@ typedef enum rtx_status {
 
 /* ---- host-side scene data ------------------------------------------------------ */
 
+enum {
+    RTX_BUILDER_HOST = 0,        /* scalar restatement of the reference builder on one host core */
+    RTX_BUILDER_DEVICE = 1       /* the same tree built by HIP kernels                           */
+};
+
 /* BVHNode as the reference lays it out (include/bvh.hpp:25-30): 64 bytes.
  * count == 0: inner node, children are `first` and `first + 1`;
  * count  > 0: leaf over indices[first .. first+count). */
@@ -114,11 +119,6 @@ void rtx_host_scene_free(rtx_host_scene *hs);
 
 /* ---- BVH build ------------------------------------------------------------------- */
 
-enum {
-    RTX_BUILDER_HOST = 0,        /* scalar restatement of the reference builder on one host core */
-    RTX_BUILDER_DEVICE = 1       /* the same tree built by HIP kernels                           */
-};
-
 /* BVH::BVH (include/bvh.hpp:84-98: updateNodeBounds, subdivide, findBestSplitPlane,
  * :100-162,236-305) over n_triangles triangles given as 9 doubles each.  Both builders
  * return the reference's arrays bit for bit: nodes_out (room for 2n-1 records, *n_nodes_out
@@ -142,6 +142,16 @@ typedef struct rtx_scene rtx_scene;
  * Takes the place of passing `Scene` by value to each render thread
  * (src/main.cpp:46). */
 int rtx_scene_create(const rtx_scene_desc *desc, rtx_scene **out);
+/* The same with the builder named (RTX_BUILDER_*, below) for a desc without a BVH.
+ * rtx_scene_create uses RTX_BUILDER_DEVICE: the vertices are uploaded once, the tree is
+ * built and converted to the render layout on the device and never travels back; the
+ * result is the same scene, bit for bit, as with RTX_BUILDER_HOST.  A desc that brings its
+ * own BVH is validated on the host and uploaded as is, whatever `builder` says. */
+int rtx_scene_create_with_builder(const rtx_scene_desc *desc, int32_t builder, rtx_scene **out);
+/* Seconds the BVH build took inside the create call (device builder: kernels only);
+ * 0 when the caller supplied the tree.  What Scene::Scene prints as "[ BVH ]"
+ * (include/scene.hpp:47-51). */
+double rtx_scene_build_seconds(const rtx_scene *scene);
 int rtx_scene_create_from_host(const rtx_host_scene *hs, int32_t device, rtx_scene **out);
 void rtx_scene_destroy(rtx_scene *scene);
 /* Bytes of HBM held by the scene (nodes + triangles + materials + lights). */

@@ -104,7 +104,7 @@ EXPORTS = (
     "rtx_scene_create", "rtx_scene_create_from_host", "rtx_scene_destroy", "rtx_scene_device_bytes",
     "rtx_render_params_default", "rtx_output_pixels", "rtx_render", "rtx_render_device", "rtx_untile",
     "rtx_save_ppm", "rtx_selftest_division", "rtx_last_error", "rtx_version",
-    "rtx_bvh_build", "rtx_host_scene_rebuild_bvh",
+    "rtx_bvh_build", "rtx_host_scene_rebuild_bvh", "rtx_scene_create_with_builder", "rtx_scene_build_seconds",
 )
 
 _lib = None
@@ -140,6 +140,9 @@ def lib() -> C.CDLL:
     L.rtx_host_scene_free.argtypes = [vp]
     L.rtx_host_scene_free.restype = None
     L.rtx_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(vp)]
+    L.rtx_scene_create_with_builder.argtypes = [C.POINTER(SceneDesc), C.c_int32, C.POINTER(vp)]
+    L.rtx_scene_build_seconds.argtypes = [vp]
+    L.rtx_scene_build_seconds.restype = C.c_double
     L.rtx_scene_create_from_host.argtypes = [vp, C.c_int32, C.POINTER(vp)]
     L.rtx_scene_destroy.argtypes = [vp]
     L.rtx_scene_destroy.restype = None
@@ -199,6 +202,51 @@ def make_params(width: int, height: int, *, depth: int = 3, spp: int = 1, seed: 
     return p
 
 
+def desc_from_arrays(vertices, colors, specularity, reflectivity, *, camera_position, camera_rotation_deg=(0, 0, 0),
+                     viewport=(1, 1, 1), background=(255, 255, 255), ambient=0.2, point_lights=(), directional_lights=(),
+                     nodes=None, indices=None, normals=None, device=-1):
+    """An rtx_scene_desc over numpy arrays; returns (desc, objects that must stay alive while it is used)."""
+    v = np.ascontiguousarray(vertices, dtype=np.float64).reshape(-1, 9)
+    n = v.shape[0]
+    col = np.ascontiguousarray(colors, dtype=np.int32).reshape(n, 3)
+    spec = np.ascontiguousarray(specularity, dtype=np.int32).reshape(n)
+    refl = np.ascontiguousarray(reflectivity, dtype=np.float64).reshape(n)
+    d = SceneDesc()
+    d.n_triangles = n
+    d.vertices, d.colors = _dptr(v, C.c_double), _dptr(col, C.c_int32)
+    d.specularity, d.reflectivity = _dptr(spec, C.c_int32), _dptr(refl, C.c_double)
+    keep = [v, col, spec, refl]
+    if normals is not None:
+        nr = np.ascontiguousarray(normals, dtype=np.float64).reshape(n, 3)
+        d.normals = _dptr(nr, C.c_double)
+        keep.append(nr)
+    if nodes is not None:
+        nd = np.ascontiguousarray(nodes)
+        ix = np.ascontiguousarray(indices, dtype=np.uint64)
+        d.n_nodes = nd.shape[0]
+        d.nodes = C.cast(nd.ctypes.data, C.POINTER(BvhNode))
+        d.indices = _dptr(ix, C.c_uint64)
+        keep += [nd, ix]
+    d.viewport[:] = viewport
+    d.camera_position[:] = camera_position
+    d.camera_rotation_deg[:] = camera_rotation_deg
+    d.background[:] = background
+    d.ambient = ambient
+    pl = (Light * max(1, len(point_lights)))()
+    for i, (inten, vec) in enumerate(point_lights):
+        pl[i].intensity = inten
+        pl[i].v[:] = vec
+    dl = (Light * max(1, len(directional_lights)))()
+    for i, (inten, vec) in enumerate(directional_lights):
+        dl[i].intensity = inten
+        dl[i].v[:] = vec
+    d.n_point_lights, d.point_lights = len(point_lights), pl
+    d.n_directional_lights, d.directional_lights = len(directional_lights), dl
+    d.device = device
+    keep += [pl, dl]
+    return d, keep
+
+
 class HostScene:
     """What the reference holds in `Scene` + `BVH` (include/scene.hpp:15-23, include/bvh.hpp:32-37)."""
 
@@ -222,44 +270,11 @@ class HostScene:
         return cls(h)
 
     @classmethod
-    def from_arrays(cls, vertices, colors, specularity, reflectivity, *, camera_position, camera_rotation_deg=(0, 0, 0),
-                    viewport=(1, 1, 1), background=(255, 255, 255), ambient=0.2, point_lights=(), directional_lights=(),
-                    nodes=None, indices=None) -> "HostScene":
-        v = np.ascontiguousarray(vertices, dtype=np.float64).reshape(-1, 9)
-        n = v.shape[0]
-        col = np.ascontiguousarray(colors, dtype=np.int32).reshape(n, 3)
-        spec = np.ascontiguousarray(specularity, dtype=np.int32).reshape(n)
-        refl = np.ascontiguousarray(reflectivity, dtype=np.float64).reshape(n)
-        d = SceneDesc()
-        d.n_triangles = n
-        d.vertices, d.colors = _dptr(v, C.c_double), _dptr(col, C.c_int32)
-        d.specularity, d.reflectivity = _dptr(spec, C.c_int32), _dptr(refl, C.c_double)
-        keep = [v, col, spec, refl]
-        if nodes is not None:
-            nd = np.ascontiguousarray(nodes)
-            ix = np.ascontiguousarray(indices, dtype=np.uint64)
-            d.n_nodes = nd.shape[0]
-            d.nodes = C.cast(nd.ctypes.data, C.POINTER(BvhNode))
-            d.indices = _dptr(ix, C.c_uint64)
-            keep += [nd, ix]
-        d.viewport[:] = viewport
-        d.camera_position[:] = camera_position
-        d.camera_rotation_deg[:] = camera_rotation_deg
-        d.background[:] = background
-        d.ambient = ambient
-        pl = (Light * max(1, len(point_lights)))()
-        for i, (inten, vec) in enumerate(point_lights):
-            pl[i].intensity = inten
-            pl[i].v[:] = vec
-        dl = (Light * max(1, len(directional_lights)))()
-        for i, (inten, vec) in enumerate(directional_lights):
-            dl[i].intensity = inten
-            dl[i].v[:] = vec
-        d.n_point_lights, d.point_lights = len(point_lights), pl
-        d.n_directional_lights, d.directional_lights = len(directional_lights), dl
-        d.device = -1
+    def from_arrays(cls, vertices, colors, specularity, reflectivity, **kw) -> "HostScene":
+        d, keep = desc_from_arrays(vertices, colors, specularity, reflectivity, **kw)
         h = C.c_void_p()
         _check(lib().rtx_host_scene_from_desc(C.byref(d), C.byref(h)))
+        del keep
         return cls(h)
 
     def desc(self) -> SceneDesc:
@@ -329,10 +344,27 @@ class Frame:
 class Scene:
     """A scene resident in one GPU's HBM."""
 
-    def __init__(self, host: HostScene, device: int = -1):
+    def __init__(self, host: HostScene | None, device: int = -1, *, _handle=None):
+        if _handle is not None:
+            self._h = _handle
+            return
         h = C.c_void_p()
         _check(lib().rtx_scene_create_from_host(host._h, device, C.byref(h)))
         self._h = h
+
+    @classmethod
+    def from_arrays(cls, vertices, colors, specularity, reflectivity, *, builder: int = BUILDER_DEVICE, **kw) -> "Scene":
+        """rtx_scene_create_with_builder(): triangles in, device scene out (BVH built by `builder`
+        unless nodes/indices are passed)."""
+        d, keep = desc_from_arrays(vertices, colors, specularity, reflectivity, **kw)
+        h = C.c_void_p()
+        _check(lib().rtx_scene_create_with_builder(C.byref(d), builder, C.byref(h)))
+        del keep
+        return cls(None, _handle=h)
+
+    @property
+    def build_seconds(self) -> float:
+        return float(lib().rtx_scene_build_seconds(self._h))
 
     @property
     def device_bytes(self) -> int:

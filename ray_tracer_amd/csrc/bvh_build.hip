@@ -34,6 +34,7 @@
 #include <vector>
 
 #include "bvh_build.h"
+#include "device_layout.h"
 
 namespace rtx {
 namespace {
@@ -741,7 +742,19 @@ __global__ __launch_bounds__(kBlock) void subtree_kernel(const double *__restric
         // updateNodeBounds (bvh.hpp:100-115) and the centroid bounds of bvh.hpp:242-250.
         // Few members: read them lane by lane into uniform values; many: butterfly reductions.
         uint64_t box[6], zero[3], cbox_k[6];
-        if (cnt <= kSerialMembers) {
+        if (cnt == 1) {
+            // a single triangle: its own box; it cannot be split (bvh.hpp:252 skips every axis)
+            const int src = __ffsll((unsigned long long)__ballot(member)) - 1;
+            const uint32_t p_src = __builtin_amdgcn_readlane(pos, src);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                box[k] = readlane64(lo[k], src);
+                box[3 + k] = readlane64(hi[k], src);
+                cbox_k[k] = cbox_k[3 + k] = 0;
+                const uint32_t zi = __builtin_amdgcn_readlane(zinfo[k], src);
+                zero[k] = zi ? ((p_src * 3 + (zi >> 1)) << 1) | (zi & 1) : 0u;
+            }
+        } else if (cnt <= kSerialMembers) {
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 box[k] = cbox_k[k] = kKeyMinInit;
@@ -792,57 +805,92 @@ __global__ __launch_bounds__(kBlock) void subtree_kernel(const double *__restric
             double cmin[3], cmax[3];
 #pragma unroll
             for (int k = 0; k < 3; k++) { cmin[k] = value_of(cbox_k[k]); cmax[k] = value_of(cbox_k[3 + k]); }
-            if (lane < kBinSlots) {
-                s_cnt[wave][lane] = 0;
-#pragma unroll
-                for (int k = 0; k < 3; k++) { s_lo[wave][lane][k] = kKeyMinInit; s_hi[wave][lane][k] = kKeyMaxInit; }
-            }
-            wave_sync();
-            if (member) {
-#pragma unroll
-                for (int ax = 0; ax < 3; ax++) {
-                    if (cmin[ax] == cmax[ax]) continue;
-                    const double scale = kBins / (cmax[ax] - cmin[ax]);
-                    size_t bb = static_cast<size_t>((c[ax] - cmin[ax]) * scale);
-                    if (bb > kBins - 1) bb = kBins - 1;
-                    const int s = ax * kBins + (int)bb;
-                    atomicAdd(&s_cnt[wave][s], 1u);
-#pragma unroll
-                    for (int k = 0; k < 3; k++) {
-                        atomicMin(&s_lo[wave][s][k], (unsigned long long)lo[k]);
-                        atomicMax(&s_hi[wave][s][k], (unsigned long long)hi[k]);
-                    }
-                }
-            }
-            wave_sync();
             // lanes 0..20: one candidate plane each (axis-major, as the reference scans them)
             const int ax = lane / (kBins - 1), plane = lane % (kBins - 1);
-            double cost = inf, cand_pos = 0;
-            if (lane < 3 * (kBins - 1)) {
-                const double lo_c = ax == 0 ? cmin[0] : ax == 1 ? cmin[1] : cmin[2];
-                const double hi_c = ax == 0 ? cmax[0] : ax == 1 ? cmax[1] : cmax[2];
-                if (lo_c != hi_c) {
-                    double llo[3] = {inf, inf, inf}, lhi[3] = {-inf, -inf, -inf};
-                    double rlo[3] = {inf, inf, inf}, rhi[3] = {-inf, -inf, -inf};
-                    int lcount = 0, rcount = 0;
+            const double lo_c = ax == 0 ? cmin[0] : ax == 1 ? cmin[1] : cmin[2];
+            const double hi_c = ax == 0 ? cmax[0] : ax == 1 ? cmax[1] : cmax[2];
+            const bool candidate = lane < 3 * (kBins - 1) && lo_c != hi_c;
+            double llo[3] = {inf, inf, inf}, lhi[3] = {-inf, -inf, -inf};
+            double rlo[3] = {inf, inf, inf}, rhi[3] = {-inf, -inf, -inf};
+            int lcount = 0, rcount = 0;
+            if (cnt <= kSerialMembers) {
+                // few members: every candidate lane sorts each member to its side directly
+                const double scale = kBins / (hi_c - lo_c);
+                uint64_t todo = __ballot(member);
+                while (todo) {
+                    const int src = __ffsll((unsigned long long)todo) - 1;
+                    todo &= todo - 1;
+                    const double c0 = __longlong_as_double((long long)readlane64((uint64_t)__double_as_longlong(c[0]), src));
+                    const double c1 = __longlong_as_double((long long)readlane64((uint64_t)__double_as_longlong(c[1]), src));
+                    const double c2 = __longlong_as_double((long long)readlane64((uint64_t)__double_as_longlong(c[2]), src));
+                    const double cs = ax == 0 ? c0 : ax == 1 ? c1 : c2;
+                    size_t bb = candidate ? static_cast<size_t>((cs - lo_c) * scale) : 0;
+                    if (bb > kBins - 1) bb = kBins - 1;
+                    const bool left = (int)bb <= plane;
+                    if (left) lcount++; else rcount++;
+                    // (min/max by value: the sign of a zero cannot change an area)
+                    if (left) {
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            llo[k] = __builtin_fmin(llo[k], value_of(readlane64(lo[k], src)));
+                            lhi[k] = __builtin_fmax(lhi[k], value_of(readlane64(hi[k], src)));
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            rlo[k] = __builtin_fmin(rlo[k], value_of(readlane64(lo[k], src)));
+                            rhi[k] = __builtin_fmax(rhi[k], value_of(readlane64(hi[k], src)));
+                        }
+                    }
+                }
+            } else {
+                // bins in LDS (bvh.hpp:259-266), then the sweep of bvh.hpp:268-290 per candidate
+                if (lane < kBinSlots) {
+                    s_cnt[wave][lane] = 0;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) { s_lo[wave][lane][k] = kKeyMinInit; s_hi[wave][lane][k] = kKeyMaxInit; }
+                }
+                wave_sync();
+                if (member) {
+#pragma unroll
+                    for (int x = 0; x < 3; x++) {
+                        if (cmin[x] == cmax[x]) continue;
+                        const double scale = kBins / (cmax[x] - cmin[x]);
+                        size_t bb = static_cast<size_t>((c[x] - cmin[x]) * scale);
+                        if (bb > kBins - 1) bb = kBins - 1;
+                        const int slot = x * kBins + (int)bb;
+                        atomicAdd(&s_cnt[wave][slot], 1u);
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            atomicMin(&s_lo[wave][slot][k], (unsigned long long)lo[k]);
+                            atomicMax(&s_hi[wave][slot][k], (unsigned long long)hi[k]);
+                        }
+                    }
+                }
+                wave_sync();
+                if (candidate) {
                     for (int bb = 0; bb < kBins; bb++) {
-                        const int s = ax * kBins + bb;
-                        const int bc = (int)s_cnt[wave][s];
+                        const int slot = ax * kBins + bb;
+                        const int bc = (int)s_cnt[wave][slot];
                         if (!bc) continue;
                         const bool left = bb <= plane;
                         if (left) lcount += bc; else rcount += bc;
 #pragma unroll
                         for (int k = 0; k < 3; k++) {
-                            const double bl = value_of(s_lo[wave][s][k]), bh = value_of(s_hi[wave][s][k]);
+                            const double bl = value_of(s_lo[wave][slot][k]), bh = value_of(s_hi[wave][slot][k]);
                             if (left) { llo[k] = llo[k] < bl ? llo[k] : bl; lhi[k] = lhi[k] > bh ? lhi[k] : bh; }
                             else { rlo[k] = rlo[k] < bl ? rlo[k] : bl; rhi[k] = rhi[k] > bh ? rhi[k] : bh; }
                         }
                     }
-                    const double v = lcount * half_area(llo, lhi) + rcount * half_area(rlo, rhi);
-                    if (v < inf) cost = v;               // NaN and +inf never win (bvh.hpp:297)
-                    const double width = (hi_c - lo_c) / kBins;
-                    cand_pos = lo_c + width * static_cast<double>(plane + 1);
                 }
+                wave_sync();
+            }
+            double cost = inf, cand_pos = 0;
+            if (candidate) {
+                const double v = lcount * half_area(llo, lhi) + rcount * half_area(rlo, rhi);
+                if (v < inf) cost = v;                   // NaN and +inf never win (bvh.hpp:297)
+                const double width = (hi_c - lo_c) / kBins;
+                cand_pos = lo_c + width * static_cast<double>(plane + 1);
             }
             // smallest cost; on a tie the candidate the sequential scan meets first
             double bc = cost;
@@ -853,7 +901,6 @@ __global__ __launch_bounds__(kBlock) void subtree_kernel(const double *__restric
                 best_axis = bl / (kBins - 1);
                 best_pos = shfl_f64(cand_pos, bl);
             }
-            wave_sync();
         }
         double blo[3], bhi[3];
 #pragma unroll
@@ -979,8 +1026,13 @@ inline uint32_t blocks_for(uint64_t items, uint32_t per_block = kBlock) { return
         if (e_ != hipSuccess) { *err = std::string(#expr) + ": " + hipGetErrorString(e_); return RTX_ERR_DEVICE; } \
     } while (0)
 
-int build_bvh_device(const double *vertices, uint64_t n64, rtx_bvh_node *nodes_out, uint64_t *indices_out,
-                     uint64_t *n_nodes_out, int32_t *depth_out, double *device_ms_out, std::string *err) {
+struct DeviceBvh::Impl {
+    DeviceBuffers buf;
+};
+DeviceBvh::DeviceBvh() = default;
+DeviceBvh::~DeviceBvh() { delete impl; }
+
+int build_bvh_resident(const double *vertices, uint64_t n64, DeviceBvh *out, std::string *err) {
     if (n64 == 0) { *err = "cannot build a BVH over zero triangles"; return RTX_ERR_INVALID; }
     if (n64 >= (1ull << 28)) { *err = "more than 2^28 triangles"; return RTX_ERR_UNSUPPORTED; }
     const uint32_t n = (uint32_t)n64;
@@ -989,7 +1041,9 @@ int build_bvh_device(const double *vertices, uint64_t n64, rtx_bvh_node *nodes_o
     const uint32_t top_cap = n / 8 + 1024;
     const uint32_t cap = top_cap + 2 * n;            // + 2m-2 reserved ids per small root
     const uint32_t chunks = blocks_for(n, kScanChunk);
-    DeviceBuffers buf;
+    delete out->impl;
+    out->impl = new DeviceBvh::Impl;
+    DeviceBuffers &buf = out->impl->buf;
     double *V, *C;
     uint32_t *idx[2], *node_of[2], *local, *sums, *holes, *fills, *starts;
     uint8_t *flag;
@@ -1111,13 +1165,118 @@ int build_bvh_device(const double *vertices, uint64_t n64, rtx_bvh_node *nodes_o
     HIP_TRY_B(hipGetLastError());
     const uint64_t n_nodes = 1 + 2 * (uint64_t)inner;
     if (n_nodes > 2 * (uint64_t)n - 1) { *err = "BVH build: inconsistent node count"; return RTX_ERR_DEVICE; }
-    HIP_TRY_B(hipMemcpy(nodes_out, d_out, (size_t)n_nodes * sizeof(rtx_bvh_node), hipMemcpyDeviceToHost));
-    HIP_TRY_B(hipMemcpy(indices_out, d_indices, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
     float ms = 0;
     HIP_TRY_B(hipEventElapsedTime(&ms, ev0, ev1));
-    *n_nodes_out = n_nodes;
-    *depth_out = depth;
-    *device_ms_out = ms;
+    out->nodes = d_out;
+    out->indices = idx[cur];
+    out->indices64 = d_indices;
+    out->vertices = V;
+    out->n_triangles = n;
+    out->n_nodes = n_nodes;
+    out->depth = depth;
+    out->device_ms = ms;
+    return RTX_OK;
+}
+
+int build_bvh_device(const double *vertices, uint64_t n, rtx_bvh_node *nodes_out, uint64_t *indices_out,
+                     uint64_t *n_nodes_out, int32_t *depth_out, double *device_ms_out, std::string *err) {
+    DeviceBvh bvh;
+    if (int rc = build_bvh_resident(vertices, n, &bvh, err)) return rc;
+    HIP_TRY_B(hipMemcpy(nodes_out, bvh.nodes, (size_t)bvh.n_nodes * sizeof(rtx_bvh_node), hipMemcpyDeviceToHost));
+    HIP_TRY_B(hipMemcpy(indices_out, bvh.indices64, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    *n_nodes_out = bvh.n_nodes;
+    *depth_out = bvh.depth;
+    *device_ms_out = bvh.device_ms;
+    return RTX_OK;
+}
+
+// ---- from the reference's arrays to the render kernel's layout, on the device -------------
+
+namespace {
+
+// Slot = reference index + 1 (slot 0: a box of NaNs that no ray enters); a leaf stamps its
+// `first` on its triangles; boxes outside the range the fast slab division admits clear *tame.
+__global__ void flatten_nodes_kernel(const rtx_bvh_node *__restrict__ in, uint32_t n_nodes, DevNode *__restrict__ out,
+                                     DevTri *__restrict__ tris, int32_t *__restrict__ tame) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i == 0) {
+        DevNode d{};
+        const double nan = __longlong_as_double(0x7ff8000000000000ll);
+        for (int k = 0; k < 3; k++) { d.bmin[k] = nan; d.bmax[k] = nan; }
+        out[0] = d;
+    }
+    if (i >= n_nodes) return;
+    const rtx_bvh_node h = in[i];
+    DevNode d{};
+    bool ok = true;
+    for (int k = 0; k < 3; k++) {
+        d.bmin[k] = h.bmin[k];
+        d.bmax[k] = h.bmax[k];
+        const double a = fabs(h.bmin[k]), b = fabs(h.bmax[k]);
+        ok = ok && (a == 0.0 || (a >= 0x1p-300 && a <= 0x1p300)) && (b == 0.0 || (b >= 0x1p-300 && b <= 0x1p300)) &&
+             h.bmin[k] <= h.bmax[k];
+    }
+    d.count = (uint32_t)h.count;
+    d.first = h.count == 0 ? (uint32_t)(h.first + 1) : (uint32_t)h.first;
+    out[i + 1] = d;
+    if (!ok) atomicAnd(tame, 0);
+    for (uint64_t j = 0; j < h.count; j++) tris[h.first + j].leaf_first = (uint32_t)h.first;
+}
+
+// Triangle records in BVH::indices order; the Triangle ctor's normal (triangle.hpp:21-23)
+// when the caller gave none, and d = -(n . v0) (triangle.hpp:39).
+__global__ void flatten_tris_kernel(const double *__restrict__ V, const double *__restrict__ normals,
+                                    const int32_t *__restrict__ colors, const int32_t *__restrict__ spec,
+                                    const double *__restrict__ refl, const uint32_t *__restrict__ idx, uint32_t n,
+                                    DevTri *__restrict__ tris, DevMat *__restrict__ mats) {
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t id = idx[p];
+    const double *v = V + 9 * (size_t)id;
+    DevTri t{};
+    for (int k = 0; k < 3; k++) { t.v0[k] = v[k]; t.v1[k] = v[3 + k]; t.v2[k] = v[6 + k]; }
+    if (normals) {
+        for (int k = 0; k < 3; k++) t.n[k] = normals[3 * (size_t)id + k];
+    } else {
+        const double ax = v[3] - v[0], ay = v[4] - v[1], az = v[5] - v[2];
+        const double bx = v[6] - v[0], by = v[7] - v[1], bz = v[8] - v[2];
+        const double cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+        const double len = sqrt(cx * cx + cy * cy + cz * cz);
+        t.n[0] = cx / len;
+        t.n[1] = cy / len;
+        t.n[2] = cz / len;
+    }
+    t.d = -(t.n[0] * v[0] + t.n[1] * v[1] + t.n[2] * v[2]);
+    t.orig_id = id;
+    const uint32_t keep = tris[p].leaf_first;      // written by flatten_nodes_kernel
+    t.leaf_first = keep;
+    tris[p] = t;
+    DevMat m{};
+    for (int k = 0; k < 3; k++) m.color[k] = colors[3 * (size_t)id + k];
+    m.specularity = spec[id];
+    m.reflectivity = refl[id];
+    mats[p] = m;
+}
+
+}  // namespace
+
+int flatten_scene_device(const DeviceBvh &bvh, const double *d_normals, const int32_t *d_colors, const int32_t *d_spec,
+                         const double *d_refl, DevNode *d_nodes, DevTri *d_tris, DevMat *d_mats, int32_t *tame_out,
+                         double root_box[6], std::string *err) {
+    int32_t *d_tame = nullptr;
+    HIP_TRY_B(hipMalloc(&d_tame, sizeof(int32_t)));
+    struct Free { void *p; ~Free() { (void)hipFree(p); } } guard{d_tame};
+    const int32_t one = 1;
+    HIP_TRY_B(hipMemcpy(d_tame, &one, sizeof one, hipMemcpyHostToDevice));
+    const uint32_t n = (uint32_t)bvh.n_triangles, m = (uint32_t)bvh.n_nodes;
+    hipLaunchKernelGGL(flatten_nodes_kernel, dim3(blocks_for(m)), dim3(kBlock), 0, nullptr, bvh.nodes, m, d_nodes, d_tris, d_tame);
+    hipLaunchKernelGGL(flatten_tris_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, nullptr, bvh.vertices, d_normals, d_colors, d_spec,
+                       d_refl, bvh.indices, n, d_tris, d_mats);
+    HIP_TRY_B(hipGetLastError());
+    rtx_bvh_node root;
+    HIP_TRY_B(hipMemcpy(&root, bvh.nodes, sizeof root, hipMemcpyDeviceToHost));
+    HIP_TRY_B(hipMemcpy(tame_out, d_tame, sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 3; k++) { root_box[k] = root.bmin[k]; root_box[3 + k] = root.bmax[k]; }
     return RTX_OK;
 }
 

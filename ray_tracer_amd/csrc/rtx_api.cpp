@@ -39,6 +39,7 @@ struct rtx_scene {
     std::vector<int64_t> order_key;
     uint64_t bytes = 0;
     uint64_t n_triangles = 0;
+    double build_seconds = 0.0;   // BVH build inside rtx_scene_create*, 0 when the caller brought the tree
     int cu_count = 256;
     std::mutex lock;
 };
@@ -81,6 +82,68 @@ int finish_host_scene(rtx_host_scene *hs, bool have_normals, bool have_bvh, int 
         // Scene::Scene prints the build time in seconds (scene.hpp:49-51)
         if (verbose) printf("[ BVH ] %g seconds.\n", std::floor(s.bvh_seconds * 1000.0) / 1000.0);
     }
+    return RTX_OK;
+}
+
+// Camera, lights and the other per-scene constants of a device scene whose node,
+// triangle and material arrays are in place.
+struct SceneCommon {
+    const double *viewport, *camera_position, *camera_rotation_deg;
+    const int32_t *background;
+    double ambient;
+    const rtx_light *point_lights;
+    uint32_t n_point;
+    const rtx_light *directional_lights;
+    uint32_t n_directional;
+};
+
+int finish_device_scene(rtx_scene *sc, const SceneCommon &c, uint64_t n, uint64_t m, const double root_box[6], bool boxes_tame,
+                        int32_t bvh_depth) {
+    sc->n_triangles = n;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sc->device) == hipSuccess && cus > 0) sc->cu_count = cus;
+    std::vector<rtx::DevLight> lights;
+    for (uint32_t i = 0; i < c.n_point; i++) lights.push_back({c.point_lights[i].intensity, {c.point_lights[i].v[0], c.point_lights[i].v[1], c.point_lights[i].v[2]}});
+    for (uint32_t i = 0; i < c.n_directional; i++) lights.push_back({c.directional_lights[i].intensity, {c.directional_lights[i].v[0], c.directional_lights[i].v[1], c.directional_lights[i].v[2]}});
+    const size_t light_bytes = lights.size() * sizeof(rtx::DevLight);
+    HIP_TRY(hipMalloc(&sc->d_lights, light_bytes ? light_bytes : 16));
+    if (light_bytes) HIP_TRY(hipMemcpy(sc->d_lights, lights.data(), light_bytes, hipMemcpyHostToDevice));
+    sc->bytes += light_bytes;
+    rtx::DevScene &d = sc->dev;
+    d.nodes = (const rtx::DevNode *)sc->d_nodes;
+    d.tris = (const rtx::DevTri *)sc->d_tris;
+    d.mats = (const rtx::DevMat *)sc->d_mats;
+    d.lights = (const rtx::DevLight *)sc->d_lights;
+    d.n_nodes = (uint32_t)(m + 1);
+    d.n_tris = (uint32_t)n;
+    d.n_point = c.n_point;
+    d.n_dir = c.n_directional;
+    double scale = 0;
+    for (int k = 0; k < 3; k++) {
+        d.cam[k] = c.camera_position[k];
+        d.viewport[k] = c.viewport[k];
+        d.bg[k] = c.background[k];
+        const double a = std::fabs(root_box[k]), b = std::fabs(root_box[3 + k]);
+        if (a > scale) scale = a;
+        if (b > scale) scale = b;
+    }
+    d.scene_scale = scale;
+    // see RayDiv in rtx_kernels.hip: the slab test may replace its divisions only while
+    // every coordinate it subtracts is 0 or well inside the exponent range, and boxes are
+    // not inverted
+    auto tame = [](double v) { return v == 0.0 || (std::fabs(v) >= 0x1p-300 && std::fabs(v) <= 0x1p300); };
+    bool fast_ok = boxes_tame;
+    for (int k = 0; k < 3; k++) fast_ok = fast_ok && tame(c.camera_position[k]);
+    d.fast_div_ok = fast_ok ? 1 : 0;
+    // Vector3::rotateX/Y/Z call cos(radians) and sin(radians) with
+    // radians = (degrees / 180.0) * M_PI (util.hpp:12-14); same libm, same bits
+    const double rx = (c.camera_rotation_deg[0] / 180.0) * M_PI, ry = (c.camera_rotation_deg[1] / 180.0) * M_PI,
+                 rz = (c.camera_rotation_deg[2] / 180.0) * M_PI;
+    d.cx = std::cos(rx); d.sx = std::sin(rx);
+    d.cy = std::cos(ry); d.sy = std::sin(ry);
+    d.cz = std::cos(rz); d.sz = std::sin(rz);
+    d.ambient = c.ambient;
+    d.bvh_depth = bvh_depth;
     return RTX_OK;
 }
 
@@ -365,20 +428,11 @@ int rtx_scene_create_from_host(const rtx_host_scene *hs, int32_t device, rtx_sce
         const rtx_bvh_node &h = s.nodes[i];
         for (uint64_t j = 0; j < h.count; j++) tris[h.first + j].leaf_first = (uint32_t)h.first;
     }
-    std::vector<rtx::DevLight> lights;
-    for (const rtx_light &l : s.point_lights) lights.push_back({l.intensity, {l.v[0], l.v[1], l.v[2]}});
-    for (const rtx_light &l : s.directional_lights) lights.push_back({l.intensity, {l.v[0], l.v[1], l.v[2]}});
-
     DeviceGuard guard(device);
     if (!guard.ok) return fail(RTX_ERR_DEVICE, "cannot select the device");
     rtx_scene *sc = new (std::nothrow) rtx_scene;
     if (!sc) return fail(RTX_ERR_NOMEM, "out of host memory");
     sc->device = device;
-    sc->n_triangles = n;
-    {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) sc->cu_count = cus;
-    }
     auto upload = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
         if (e != hipSuccess) return e;
@@ -388,60 +442,109 @@ int rtx_scene_create_from_host(const rtx_host_scene *hs, int32_t device, rtx_sce
     hipError_t e = upload(&sc->d_nodes, nodes.data(), nodes.size() * sizeof(rtx::DevNode));
     if (e == hipSuccess) e = upload(&sc->d_tris, tris.data(), n * sizeof(rtx::DevTri));
     if (e == hipSuccess) e = upload(&sc->d_mats, mats.data(), n * sizeof(rtx::DevMat));
-    if (e == hipSuccess) e = upload(&sc->d_lights, lights.data(), lights.size() * sizeof(rtx::DevLight));
     if (e != hipSuccess) {
         rtx_scene_destroy(sc);
         return fail(RTX_ERR_DEVICE, std::string("scene upload: ") + hipGetErrorString(e));
     }
-    rtx::DevScene &d = sc->dev;
-    d.nodes = (const rtx::DevNode *)sc->d_nodes;
-    d.tris = (const rtx::DevTri *)sc->d_tris;
-    d.mats = (const rtx::DevMat *)sc->d_mats;
-    d.lights = (const rtx::DevLight *)sc->d_lights;
-    d.n_nodes = (uint32_t)(m + 1);
-    d.n_tris = (uint32_t)n;
-    d.n_point = (uint32_t)s.point_lights.size();
-    d.n_dir = (uint32_t)s.directional_lights.size();
-    double scale = 0;
-    for (int k = 0; k < 3; k++) {
-        d.cam[k] = s.camera_position[k];
-        d.viewport[k] = s.viewport[k];
-        d.bg[k] = s.background[k];
-        double a = std::fabs(s.nodes[0].bmin[k]), b = std::fabs(s.nodes[0].bmax[k]);
-        if (a > scale) scale = a;
-        if (b > scale) scale = b;
-    }
-    d.scene_scale = scale;
-    // see RayDiv in rtx_kernels.hip: the slab test may replace its divisions only while
-    // every coordinate it subtracts is 0 or well inside the exponent range, and boxes are
-    // not inverted
     auto tame = [](double v) { return v == 0.0 || (std::fabs(v) >= 0x1p-300 && std::fabs(v) <= 0x1p300); };
-    bool fast_ok = true;
+    bool boxes_tame = true;
     for (const rtx_bvh_node &h : s.nodes)
-        for (int k = 0; k < 3; k++) fast_ok = fast_ok && tame(h.bmin[k]) && tame(h.bmax[k]) && h.bmin[k] <= h.bmax[k];
-    for (int k = 0; k < 3; k++) fast_ok = fast_ok && tame(s.camera_position[k]);
-    d.fast_div_ok = fast_ok ? 1 : 0;
-    // Vector3::rotateX/Y/Z call cos(radians) and sin(radians) with
-    // radians = (degrees / 180.0) * M_PI (util.hpp:12-14); same libm, same bits
-    const double rx = (s.camera_rotation_deg[0] / 180.0) * M_PI, ry = (s.camera_rotation_deg[1] / 180.0) * M_PI,
-                 rz = (s.camera_rotation_deg[2] / 180.0) * M_PI;
-    d.cx = std::cos(rx); d.sx = std::sin(rx);
-    d.cy = std::cos(ry); d.sy = std::sin(ry);
-    d.cz = std::cos(rz); d.sz = std::sin(rz);
-    d.ambient = s.ambient;
-    d.bvh_depth = s.bvh_depth;
+        for (int k = 0; k < 3; k++) boxes_tame = boxes_tame && tame(h.bmin[k]) && tame(h.bmax[k]) && h.bmin[k] <= h.bmax[k];
+    const double root_box[6] = {s.nodes[0].bmin[0], s.nodes[0].bmin[1], s.nodes[0].bmin[2],
+                                s.nodes[0].bmax[0], s.nodes[0].bmax[1], s.nodes[0].bmax[2]};
+    const SceneCommon common{s.viewport, s.camera_position, s.camera_rotation_deg, s.background, s.ambient,
+                             s.point_lights.data(), (uint32_t)s.point_lights.size(),
+                             s.directional_lights.data(), (uint32_t)s.directional_lights.size()};
+    if (int rc = finish_device_scene(sc, common, n, m, root_box, boxes_tame, s.bvh_depth)) {
+        rtx_scene_destroy(sc);
+        return rc;
+    }
     *out = sc;
     return RTX_OK;
 }
 
-int rtx_scene_create(const rtx_scene_desc *desc, rtx_scene **out) {
+// A scene whose BVH is built and flattened on the device: the vertices go up once, the
+// tree never comes back to the host.
+static int create_scene_built_on_device(const rtx_scene_desc *d, rtx_scene **out) {
+    const uint64_t n = d->n_triangles;
+    if (n == 0) return fail(RTX_ERR_INVALID, "scene has no triangles");
+    if (n >= (1ull << 28)) return fail(RTX_ERR_UNSUPPORTED, "more than 2^28 triangles or BVH nodes");
+    if (!d->vertices || !d->colors || !d->specularity || !d->reflectivity) return fail(RTX_ERR_INVALID, "triangle arrays missing");
+    if ((d->n_point_lights && !d->point_lights) || (d->n_directional_lights && !d->directional_lights)) return fail(RTX_ERR_INVALID, "light arrays missing");
+    if ((uint64_t)d->n_point_lights + d->n_directional_lights > 0xffff) return fail(RTX_ERR_UNSUPPORTED, "more than 65535 lights");
+    int ndev = 0, device = d->device;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    if (device >= ndev) return fail(RTX_ERR_INVALID, "device ordinal out of range");
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(RTX_ERR_DEVICE, "cannot select the device");
+
+    std::string err;
+    rtx::DeviceBvh bvh;
+    if (int rc = rtx::build_bvh_resident(d->vertices, n, &bvh, &err)) return fail(rc, err);
+    const uint64_t m = bvh.n_nodes;
+    if (m + 1 >= (1ull << 28)) return fail(RTX_ERR_UNSUPPORTED, "more than 2^28 triangles or BVH nodes");
+
+    rtx_scene *sc = new (std::nothrow) rtx_scene;
+    if (!sc) return fail(RTX_ERR_NOMEM, "out of host memory");
+    sc->device = device;
+    struct Temp { void *p = nullptr; ~Temp() { (void)hipFree(p); } } t_normals, t_colors, t_spec, t_refl;
+    auto stage = [&](Temp &t, const void *src, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(&t.p, bytes);
+        return e != hipSuccess ? e : hipMemcpy(t.p, src, bytes, hipMemcpyHostToDevice);
+    };
+    hipError_t e = hipMalloc(&sc->d_nodes, (m + 1) * sizeof(rtx::DevNode));
+    if (e == hipSuccess) e = hipMalloc(&sc->d_tris, n * sizeof(rtx::DevTri));
+    if (e == hipSuccess) e = hipMalloc(&sc->d_mats, n * sizeof(rtx::DevMat));
+    if (e == hipSuccess && d->normals) e = stage(t_normals, d->normals, 3 * n * sizeof(double));
+    if (e == hipSuccess) e = stage(t_colors, d->colors, 3 * n * sizeof(int32_t));
+    if (e == hipSuccess) e = stage(t_spec, d->specularity, n * sizeof(int32_t));
+    if (e == hipSuccess) e = stage(t_refl, d->reflectivity, n * sizeof(double));
+    if (e != hipSuccess) {
+        rtx_scene_destroy(sc);
+        return fail(RTX_ERR_DEVICE, std::string("scene upload: ") + hipGetErrorString(e));
+    }
+    sc->bytes = (m + 1) * sizeof(rtx::DevNode) + n * (sizeof(rtx::DevTri) + sizeof(rtx::DevMat));
+    int32_t boxes_tame = 0;
+    double root_box[6];
+    int rc = rtx::flatten_scene_device(bvh, (const double *)t_normals.p, (const int32_t *)t_colors.p, (const int32_t *)t_spec.p,
+                                       (const double *)t_refl.p, (rtx::DevNode *)sc->d_nodes, (rtx::DevTri *)sc->d_tris,
+                                       (rtx::DevMat *)sc->d_mats, &boxes_tame, root_box, &err);
+    if (rc != RTX_OK) {
+        rtx_scene_destroy(sc);
+        return fail(rc, err);
+    }
+    const SceneCommon common{d->viewport, d->camera_position, d->camera_rotation_deg, d->background, d->ambient,
+                             d->point_lights, d->n_point_lights, d->directional_lights, d->n_directional_lights};
+    rc = finish_device_scene(sc, common, n, m, root_box, boxes_tame != 0, bvh.depth);
+    if (rc != RTX_OK) {
+        rtx_scene_destroy(sc);
+        return rc;
+    }
+    sc->build_seconds = bvh.device_ms * 1e-3;
+    *out = sc;
+    return RTX_OK;
+}
+
+int rtx_scene_create_with_builder(const rtx_scene_desc *desc, int32_t builder, rtx_scene **out) {
     if (!desc || !out) return fail(RTX_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    const bool have_bvh = desc->n_nodes != 0 || desc->nodes || desc->indices;
+    if (builder != RTX_BUILDER_HOST && builder != RTX_BUILDER_DEVICE) return fail(RTX_ERR_INVALID, "unknown BVH builder");
+    if (!have_bvh && builder == RTX_BUILDER_DEVICE) return create_scene_built_on_device(desc, out);
     rtx_host_scene *hs = nullptr;
     if (int rc = rtx_host_scene_from_desc(desc, &hs)) return rc;
     int rc = rtx_scene_create_from_host(hs, desc->device, out);
+    if (rc == RTX_OK && !have_bvh) (*out)->build_seconds = hs->s.bvh_seconds;
     rtx_host_scene_free(hs);
     return rc;
 }
+
+int rtx_scene_create(const rtx_scene_desc *desc, rtx_scene **out) {
+    return rtx_scene_create_with_builder(desc, RTX_BUILDER_DEVICE, out);
+}
+
+double rtx_scene_build_seconds(const rtx_scene *sc) { return sc ? sc->build_seconds : 0.0; }
 
 void rtx_scene_destroy(rtx_scene *sc) {
     if (!sc) return;

@@ -82,3 +82,41 @@ def test_full_size_dragon_tree():
     dev = rt.build_bvh(a["vertices"], rt.BUILDER_DEVICE)
     assert dev["nodes"].tobytes() == a["nodes"].tobytes()
     assert np.array_equal(dev["indices"], a["indices"])
+
+
+def _render_both(scene, w, h):
+    out = []
+    for mode in (rt.TRAVERSAL_REFERENCE, rt.TRAVERSAL_PRUNED):
+        f = scene.render(w, h, traversal=mode, want_stats=True)
+        out.append((f.rgb.copy(), f.hit.copy(), f.stats.as_dict()))
+    return out
+
+
+def test_scene_built_on_device_equals_scene_from_host_tree():
+    """rtx_scene_create (tree built and flattened on the device, normals computed there) against
+    rtx_scene_create_from_host (host tree, host normals): same pixels, ids and work counters."""
+    from scenes_util import soup
+    verts, colors, spec, refl, kw = soup(21, 5000)
+    host_scene = rt.Scene(rt.HostScene.from_arrays(verts, colors, spec, refl, **kw))
+    dev_scene = rt.Scene.from_arrays(verts, colors, spec, refl, **kw)
+    assert dev_scene.build_seconds > 0
+    assert dev_scene.device_bytes == host_scene.device_bytes
+    for (rgb_a, hit_a, st_a), (rgb_b, hit_b, st_b) in zip(_render_both(host_scene, 160, 120), _render_both(dev_scene, 160, 120)):
+        assert np.array_equal(hit_a, hit_b)
+        assert np.array_equal(rgb_a, rgb_b)
+        for key in ("primary_rays", "reflection_rays", "shadow_rays", "node_visits", "triangle_tests", "leaf_visits"):
+            assert st_a[key] == st_b[key], key
+
+
+def test_scene_built_on_device_with_given_normals_and_host_builder_choice():
+    hs = rt.HostScene.load_obj(os.path.join(HERE, "golden", "teapot.obj"), "teapot")
+    a = hs.arrays()
+    kw = dict(camera_position=a["camera_position"], camera_rotation_deg=a["camera_rotation_deg"],
+              directional_lights=[(0.5, (0.0, 1.0, -1.0))], ambient=0.2)
+    ref = rt.Scene(hs).render(128, 128, traversal=rt.TRAVERSAL_REFERENCE)
+    for builder, normals in ((rt.BUILDER_DEVICE, a["normals"]), (rt.BUILDER_DEVICE, None), (rt.BUILDER_HOST, None)):
+        sc = rt.Scene.from_arrays(a["vertices"], a["colors"], a["specularity"], a["reflectivity"], builder=builder,
+                                  normals=normals, **kw)
+        f = sc.render(128, 128, traversal=rt.TRAVERSAL_REFERENCE)
+        assert np.array_equal(f.hit, ref.hit)
+        assert np.array_equal(f.rgb, ref.rgb)
