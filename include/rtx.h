@@ -95,6 +95,24 @@ typedef struct rtx_host_scene rtx_host_scene;
  * reference's "[ TRI ] n triangles." / "[ BVH ] s seconds." lines when verbose. */
 int rtx_host_scene_load_obj(const char *obj_path, const char *preset, int verbose, rtx_host_scene **out);
 
+enum {
+    RTX_LOAD_VERBOSE = 1,        /* print the reference's "[ TRI ]" / "[ BVH ]" lines                       */
+    RTX_LOAD_DEVICE_BVH = 2,     /* build the BVH with RTX_BUILDER_DEVICE (same arrays, copied back)        */
+    RTX_LOAD_TOLERANT = 4,       /* general OBJ text instead of the reference's dialect, see below          */
+    RTX_LOAD_NO_BVH = 8          /* no BVH on the host: rtx_scene_create_from_host builds it on the device  */
+};
+
+/* The call above with options.  RTX_LOAD_TOLERANT reads OBJ files the reference's loader
+ * cannot: it does what tools/denormalize.py:1-36 does before parseOBJ sees the file, in one
+ * pass over the text -- `v` records are collected first, then every `f` record contributes
+ * ONE triangle from the leading index of its first three `a`, `a/b`, `a//c` or `a/b/c`
+ * groups, negative indices count back from the end of the vertex list -- and every other
+ * record (vn, vt, o, g, s, usemtl, comments) is skipped.  Unlike the strict loader it does
+ * not repeat the last face when the file ends in a newline (include/scene.hpp:223-246 does,
+ * and the strict loader keeps that so that triangle ids match the reference's). */
+int rtx_host_scene_load_obj_ex(const char *obj_path, const char *preset, uint32_t flags, int32_t device,
+                               rtx_host_scene **out);
+
 /* The stand-in for a missing mesh: a seeded procedural closed surface with exactly
  * n_triangles - 10 faces inside the 10-triangle open box of tools/range.py:40-54,
  * framed for `preset`'s camera.  Written as an .obj in the reference's dialect when
@@ -103,6 +121,9 @@ int rtx_host_scene_load_obj(const char *obj_path, const char *preset, int verbos
  * redistributable with this repository). */
 int rtx_host_scene_standin(const char *preset, uint64_t n_triangles, uint64_t seed, const char *obj_path_out,
                            int verbose, rtx_host_scene **out);
+/* The same with RTX_LOAD_* flags (RTX_LOAD_TOLERANT has no meaning here). */
+int rtx_host_scene_standin_ex(const char *preset, uint64_t n_triangles, uint64_t seed, const char *obj_path_out,
+                              uint32_t flags, int32_t device, rtx_host_scene **out);
 
 /* Scene from caller arrays (copies them; builds normals/BVH when absent). */
 int rtx_host_scene_from_desc(const rtx_scene_desc *desc, rtx_host_scene **out);
@@ -152,6 +173,9 @@ int rtx_scene_create_with_builder(const rtx_scene_desc *desc, int32_t builder, r
  * 0 when the caller supplied the tree.  What Scene::Scene prints as "[ BVH ]"
  * (include/scene.hpp:47-51). */
 double rtx_scene_build_seconds(const rtx_scene *scene);
+/* BVH::nodesUsed (include/bvh.hpp:36) and the depth of the deepest node (root = 0) of the scene's tree. */
+uint64_t rtx_scene_bvh_nodes(const rtx_scene *scene);
+int32_t rtx_scene_bvh_depth(const rtx_scene *scene);
 int rtx_scene_create_from_host(const rtx_host_scene *hs, int32_t device, rtx_scene **out);
 void rtx_scene_destroy(rtx_scene *scene);
 /* Bytes of HBM held by the scene (nodes + triangles + materials + lights). */

@@ -104,7 +104,9 @@ EXPORTS = (
     "rtx_scene_create", "rtx_scene_create_from_host", "rtx_scene_destroy", "rtx_scene_device_bytes",
     "rtx_render_params_default", "rtx_output_pixels", "rtx_render", "rtx_render_device", "rtx_untile",
     "rtx_save_ppm", "rtx_selftest_division", "rtx_last_error", "rtx_version",
+    "rtx_host_scene_load_obj_ex", "rtx_host_scene_standin_ex",
     "rtx_bvh_build", "rtx_host_scene_rebuild_bvh", "rtx_scene_create_with_builder", "rtx_scene_build_seconds",
+    "rtx_scene_bvh_nodes", "rtx_scene_bvh_depth",
 )
 
 _lib = None
@@ -131,6 +133,8 @@ def lib() -> C.CDLL:
     L.rtx_version.restype = C.c_char_p
     L.rtx_host_scene_load_obj.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp)]
     L.rtx_host_scene_standin.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.rtx_host_scene_load_obj_ex.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_int32, C.POINTER(vp)]
+    L.rtx_host_scene_standin_ex.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_char_p, C.c_uint32, C.c_int32, C.POINTER(vp)]
     L.rtx_host_scene_from_desc.argtypes = [C.POINTER(SceneDesc), C.POINTER(vp)]
     L.rtx_host_scene_desc.argtypes = [vp, C.POINTER(SceneDesc)]
     L.rtx_host_scene_bvh_depth.argtypes = [vp]
@@ -143,6 +147,10 @@ def lib() -> C.CDLL:
     L.rtx_scene_create_with_builder.argtypes = [C.POINTER(SceneDesc), C.c_int32, C.POINTER(vp)]
     L.rtx_scene_build_seconds.argtypes = [vp]
     L.rtx_scene_build_seconds.restype = C.c_double
+    L.rtx_scene_bvh_nodes.argtypes = [vp]
+    L.rtx_scene_bvh_nodes.restype = C.c_uint64
+    L.rtx_scene_bvh_depth.argtypes = [vp]
+    L.rtx_scene_bvh_depth.restype = C.c_int32
     L.rtx_scene_create_from_host.argtypes = [vp, C.c_int32, C.POINTER(vp)]
     L.rtx_scene_destroy.argtypes = [vp]
     L.rtx_scene_destroy.restype = None
@@ -175,6 +183,7 @@ def _dptr(a: np.ndarray, ctype):
 
 NODE_DTYPE = np.dtype([("bmin", "<f8", 3), ("bmax", "<f8", 3), ("first", "<u8"), ("count", "<u8")])
 BUILDER_HOST, BUILDER_DEVICE = 0, 1
+LOAD_VERBOSE, LOAD_DEVICE_BVH, LOAD_TOLERANT, LOAD_NO_BVH = 1, 2, 4, 8
 
 
 def build_bvh(vertices, builder: int = BUILDER_DEVICE, device: int = -1) -> dict:
@@ -255,18 +264,22 @@ class HostScene:
         self._keep = None
 
     @classmethod
-    def load_obj(cls, path: str, preset: str, verbose: bool = False) -> "HostScene":
+    def load_obj(cls, path: str, preset: str, verbose: bool = False, *, device_bvh: bool = False, tolerant: bool = False,
+                 no_bvh: bool = False, device: int = -1) -> "HostScene":
         h = C.c_void_p()
-        _check(lib().rtx_host_scene_load_obj(os.fsencode(path), preset.encode(), int(verbose), C.byref(h)))
+        flags = ((LOAD_VERBOSE if verbose else 0) | (LOAD_DEVICE_BVH if device_bvh else 0) | (LOAD_TOLERANT if tolerant else 0) |
+                 (LOAD_NO_BVH if no_bvh else 0))
+        _check(lib().rtx_host_scene_load_obj_ex(os.fsencode(path), preset.encode(), flags, device, C.byref(h)))
         return cls(h)
 
     @classmethod
     def standin(cls, preset: str, n_triangles: int | None = None, seed: int = 0, obj_path_out: str | None = None,
-                verbose: bool = False) -> "HostScene":
+                verbose: bool = False, *, device_bvh: bool = False, no_bvh: bool = False, device: int = -1) -> "HostScene":
         h = C.c_void_p()
         n = SCENE_TRIANGLES[preset] if n_triangles is None else n_triangles
         out = os.fsencode(obj_path_out) if obj_path_out else None
-        _check(lib().rtx_host_scene_standin(preset.encode(), n, seed, out, int(verbose), C.byref(h)))
+        flags = (LOAD_VERBOSE if verbose else 0) | (LOAD_DEVICE_BVH if device_bvh else 0) | (LOAD_NO_BVH if no_bvh else 0)
+        _check(lib().rtx_host_scene_standin_ex(preset.encode(), n, seed, out, flags, device, C.byref(h)))
         return cls(h)
 
     @classmethod
@@ -365,6 +378,14 @@ class Scene:
     @property
     def build_seconds(self) -> float:
         return float(lib().rtx_scene_build_seconds(self._h))
+
+    @property
+    def bvh_nodes(self) -> int:
+        return int(lib().rtx_scene_bvh_nodes(self._h))
+
+    @property
+    def bvh_depth(self) -> int:
+        return int(lib().rtx_scene_bvh_depth(self._h))
 
     @property
     def device_bytes(self) -> int:

@@ -92,6 +92,62 @@ int parse_obj(const std::string &path, std::vector<double> *vertices9, std::stri
     return RTX_OK;
 }
 
+// tools/denormalize.py:1-36 + Scene::parseOBJ in one pass over the text.  The script
+// keeps the lines whose first token is `v` or `f`, writes the vertices first and rewrites
+// each face as `f i0 i1 i2` from the leading integer of its first three index groups,
+// resolving negative indices against the number of vertices in the whole file.
+int parse_obj_tolerant(const std::string &path, std::vector<double> *vertices9, std::string *err) {
+    std::string text;
+    if (!slurp(path, &text)) { *err = "Failed to open file.\n"; return RTX_ERR_IO; }
+    const char *const begin = text.c_str();
+    const char *const end = begin + text.size();
+    auto next_line = [&](const char *p) {
+        const char *q = static_cast<const char *>(memchr(p, '\n', static_cast<size_t>(end - p)));
+        return q ? q + 1 : end;
+    };
+    auto record = [&](const char *p, char id) {          // "<id><blank>" at the start of a line
+        return p + 1 < end && p[0] == id && (p[1] == ' ' || p[1] == '\t');
+    };
+    std::vector<double> pos;
+    size_t n_faces = 0;
+    for (const char *p = begin; p < end; p = next_line(p)) {
+        while (p < end && (*p == ' ' || *p == '\t')) p++;
+        if (record(p, 'v')) {
+            const char *q = p + 1;
+            for (int k = 0; k < 3; k++) {
+                char *r = nullptr;
+                const double c = strtod(q, &r);
+                if (r == q) { *err = "OBJ: vertex record is not 'v x y z'"; return RTX_ERR_UNSUPPORTED; }
+                pos.push_back(c);
+                q = r;
+            }
+        } else if (record(p, 'f')) {
+            n_faces++;
+        }
+    }
+    const long long n_vertices = static_cast<long long>(pos.size() / 3);
+    vertices9->clear();
+    vertices9->reserve(9 * n_faces);
+    for (const char *p = begin; p < end; p = next_line(p)) {
+        while (p < end && (*p == ' ' || *p == '\t')) p++;
+        if (!record(p, 'f')) continue;
+        const char *q = p + 1;
+        for (int k = 0; k < 3; k++) {
+            char *r = nullptr;
+            long long c = strtoll(q, &r, 10);
+            if (r == q) { *err = "OBJ: face record has fewer than three vertices"; return RTX_ERR_UNSUPPORTED; }
+            q = r;
+            while (q < end && *q != ' ' && *q != '\t' && *q != '\n' && *q != '\r') q++;   // the /vt/vn part of the group
+            if (c < 0) c = n_vertices + c + 1;
+            if (c < 1 || c > n_vertices) { *err = "OBJ: face references a vertex that does not exist"; return RTX_ERR_INVALID; }
+            const double *v = &pos[static_cast<size_t>(c - 1) * 3];
+            vertices9->insert(vertices9->end(), v, v + 3);
+        }
+    }
+    if (vertices9->empty()) { *err = "OBJ: no faces"; return RTX_ERR_INVALID; }
+    return RTX_OK;
+}
+
 // Triangle::Triangle, include/triangle.hpp:16-25.
 void setup_triangles(HostScene *hs, bool have_normals) {
     const uint64_t n = hs->n_triangles();

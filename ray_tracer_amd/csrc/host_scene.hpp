@@ -40,6 +40,8 @@ struct HostScene {
 
 // Each returns an rtx_status and leaves the message in `err`.
 int parse_obj(const std::string &path, std::vector<double> *vertices9, std::string *err);
+// General OBJ text: what tools/denormalize.py followed by Scene::parseOBJ accepts, each face once.
+int parse_obj_tolerant(const std::string &path, std::vector<double> *vertices9, std::string *err);
 int apply_preset(HostScene *hs, const std::string &preset, std::string *err);
 // Triangle ctor work (include/triangle.hpp:21-24) for triangles lacking it.
 void setup_triangles(HostScene *hs, bool have_normals);

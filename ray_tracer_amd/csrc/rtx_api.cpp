@@ -70,15 +70,35 @@ struct DeviceGuard {
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
-int finish_host_scene(rtx_host_scene *hs, bool have_normals, bool have_bvh, int verbose) {
+int build_into_host_scene(rtx::HostScene &s, int32_t builder, int32_t device, std::string *err) {
+    if (builder == RTX_BUILDER_HOST) return rtx::build_bvh(&s, err);
+    if (builder != RTX_BUILDER_DEVICE) { *err = "unknown BVH builder"; return RTX_ERR_INVALID; }
+    const uint64_t n = s.n_triangles();
+    if (n == 0) { *err = "cannot build a BVH over zero triangles"; return RTX_ERR_INVALID; }
+    int dev = device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) { *err = "no HIP device"; return RTX_ERR_DEVICE; }
+    DeviceGuard guard(dev);
+    if (!guard.ok) { *err = "cannot select the HIP device"; return RTX_ERR_DEVICE; }
+    s.nodes.assign(2 * n - 1, rtx_bvh_node{{0, 0, 0}, {0, 0, 0}, 0, 0});
+    s.indices.assign(n, 0);
+    uint64_t used = 0;
+    double ms = 0;
+    if (int rc = rtx::build_bvh_device(s.vertices.data(), n, s.nodes.data(), s.indices.data(), &used, &s.bvh_depth, &ms, err)) return rc;
+    s.nodes.resize(used);
+    s.bvh_seconds = ms * 1e-3;
+    return RTX_OK;
+}
+
+int finish_host_scene(rtx_host_scene *hs, bool have_normals, bool have_bvh, int verbose, int32_t builder = RTX_BUILDER_HOST,
+                      int32_t device = -1) {
     rtx::HostScene &s = hs->s;
     rtx::setup_triangles(&s, have_normals);
     std::string err;
     if (have_bvh) {
         if (int rc = rtx::validate_bvh(s, &err)) return fail(rc, err);
         s.bvh_depth = rtx::measure_bvh_depth(s.nodes);
-    } else {
-        if (int rc = rtx::build_bvh(&s, &err)) return fail(rc, err);
+    } else if (builder >= 0) {
+        if (int rc = build_into_host_scene(s, builder, device, &err)) return fail(rc, err);
         // Scene::Scene prints the build time in seconds (scene.hpp:49-51)
         if (verbose) printf("[ BVH ] %g seconds.\n", std::floor(s.bvh_seconds * 1000.0) / 1000.0);
     }
@@ -147,6 +167,11 @@ int finish_device_scene(rtx_scene *sc, const SceneCommon &c, uint64_t n, uint64_
     return RTX_OK;
 }
 
+int32_t loader_builder(uint32_t flags) {
+    if (flags & RTX_LOAD_NO_BVH) return -1;
+    return (flags & RTX_LOAD_DEVICE_BVH) ? RTX_BUILDER_DEVICE : RTX_BUILDER_HOST;
+}
+
 struct ResolvedParams {
     rtx::DevRender r{};
 };
@@ -195,27 +220,34 @@ const char *rtx_last_error(void) { return g_error.c_str(); }
 const char *rtx_version(void) { return "rtx-mi355x 0.1 (gfx950)"; }
 
 // ------------------------------------------------------------------ host scenes
-int rtx_host_scene_load_obj(const char *obj_path, const char *preset, int verbose, rtx_host_scene **out) {
+int rtx_host_scene_load_obj_ex(const char *obj_path, const char *preset, uint32_t flags, int32_t device, rtx_host_scene **out) {
     if (!obj_path || !preset || !out) return fail(RTX_ERR_INVALID, "NULL argument");
     *out = nullptr;
+    const int verbose = (flags & RTX_LOAD_VERBOSE) != 0;
     rtx_host_scene *hs = new (std::nothrow) rtx_host_scene;
     if (!hs) return fail(RTX_ERR_NOMEM, "out of host memory");
     std::string err;
-    int rc = rtx::parse_obj(obj_path, &hs->s.vertices, &err);
+    int rc = (flags & RTX_LOAD_TOLERANT) ? rtx::parse_obj_tolerant(obj_path, &hs->s.vertices, &err)
+                                         : rtx::parse_obj(obj_path, &hs->s.vertices, &err);
     // Scene::parseOBJ prints the face count (scene.hpp:248)
     if (rc == RTX_OK && verbose) printf("[ TRI ] %zu triangles.\n", hs->s.vertices.size() / 9);
     if (rc == RTX_OK) rc = rtx::apply_preset(&hs->s, preset, &err);
     if (rc != RTX_OK) { delete hs; return fail(rc, err); }
-    rc = finish_host_scene(hs, false, false, verbose);
+    rc = finish_host_scene(hs, false, false, verbose, loader_builder(flags), device);
     if (rc != RTX_OK) { delete hs; return rc; }
     *out = hs;
     return RTX_OK;
 }
 
-int rtx_host_scene_standin(const char *preset, uint64_t n_triangles, uint64_t seed, const char *obj_path_out, int verbose,
-                           rtx_host_scene **out) {
+int rtx_host_scene_load_obj(const char *obj_path, const char *preset, int verbose, rtx_host_scene **out) {
+    return rtx_host_scene_load_obj_ex(obj_path, preset, verbose ? RTX_LOAD_VERBOSE : 0, -1, out);
+}
+
+int rtx_host_scene_standin_ex(const char *preset, uint64_t n_triangles, uint64_t seed, const char *obj_path_out, uint32_t flags,
+                              int32_t device, rtx_host_scene **out) {
     if (!preset) return fail(RTX_ERR_INVALID, "NULL preset");
     if (out) *out = nullptr;
+    const int verbose = (flags & RTX_LOAD_VERBOSE) != 0;
     std::vector<double> verts;
     std::vector<uint32_t> faces;
     std::string err;
@@ -230,10 +262,15 @@ int rtx_host_scene_standin(const char *preset, uint64_t n_triangles, uint64_t se
     if (verbose) printf("[ TRI ] %zu triangles.\n", hs->s.vertices.size() / 9);
     int rc = rtx::apply_preset(&hs->s, preset, &err);
     if (rc != RTX_OK) { delete hs; return fail(rc, err); }
-    rc = finish_host_scene(hs, false, false, verbose);
+    rc = finish_host_scene(hs, false, false, verbose, loader_builder(flags), device);
     if (rc != RTX_OK) { delete hs; return rc; }
     *out = hs;
     return RTX_OK;
+}
+
+int rtx_host_scene_standin(const char *preset, uint64_t n_triangles, uint64_t seed, const char *obj_path_out, int verbose,
+                           rtx_host_scene **out) {
+    return rtx_host_scene_standin_ex(preset, n_triangles, seed, obj_path_out, verbose ? RTX_LOAD_VERBOSE : 0, -1, out);
 }
 
 int rtx_host_scene_from_desc(const rtx_scene_desc *d, rtx_host_scene **out) {
@@ -284,8 +321,8 @@ int rtx_host_scene_desc(const rtx_host_scene *hs, rtx_scene_desc *o) {
     o->specularity = s.specularity.data();
     o->reflectivity = s.reflectivity.data();
     o->n_nodes = s.nodes.size();
-    o->nodes = s.nodes.data();
-    o->indices = s.indices.data();
+    o->nodes = s.nodes.empty() ? nullptr : s.nodes.data();
+    o->indices = s.nodes.empty() ? nullptr : s.indices.data();
     for (int k = 0; k < 3; k++) {
         o->viewport[k] = s.viewport[k];
         o->camera_position[k] = s.camera_position[k];
@@ -356,31 +393,30 @@ int rtx_bvh_build(const double *vertices, uint64_t n, int32_t builder, int32_t d
 
 int rtx_host_scene_rebuild_bvh(rtx_host_scene *hs, int32_t builder, int32_t device, double *seconds_out) {
     if (!hs) return fail(RTX_ERR_INVALID, "NULL argument");
-    rtx::HostScene &s = hs->s;
-    const uint64_t n = s.n_triangles();
-    if (n == 0) return fail(RTX_ERR_INVALID, "scene has no triangles");
-    std::vector<rtx_bvh_node> nodes(2 * n - 1);
-    std::vector<uint64_t> indices(n);
-    uint64_t used = 0;
-    int32_t depth = 0;
-    double seconds = 0;
-    if (int rc = rtx_bvh_build(s.vertices.data(), n, builder, device, nodes.data(), indices.data(), &used, &depth, &seconds)) return rc;
-    nodes.resize(used);
-    s.nodes.swap(nodes);
-    s.indices.swap(indices);
-    s.bvh_depth = depth;
-    s.bvh_seconds = seconds;
-    if (seconds_out) *seconds_out = seconds;
+    std::string err;
+    if (int rc = build_into_host_scene(hs->s, builder, device, &err)) return fail(rc, err);
+    if (seconds_out) *seconds_out = hs->s.bvh_seconds;
     return RTX_OK;
 }
 
 // ------------------------------------------------------------------ device scenes
+static int create_scene_built_on_device(const rtx_scene_desc *d, rtx_scene **out);
+
 int rtx_scene_create_from_host(const rtx_host_scene *hs, int32_t device, rtx_scene **out) {
     if (!hs || !out) return fail(RTX_ERR_INVALID, "NULL argument");
     *out = nullptr;
     const rtx::HostScene &s = hs->s;
     const uint64_t n = s.n_triangles(), m = s.nodes.size();
-    if (n == 0 || m == 0) return fail(RTX_ERR_INVALID, "scene is empty");
+    if (n == 0) return fail(RTX_ERR_INVALID, "scene is empty");
+    if (m == 0) {
+        // loaded with RTX_LOAD_NO_BVH: the tree is built where it is used
+        rtx_scene_desc d;
+        if (int rc = rtx_host_scene_desc(hs, &d)) return rc;
+        d.nodes = nullptr;
+        d.indices = nullptr;
+        d.device = device;
+        return create_scene_built_on_device(&d, out);
+    }
     // traversal-stack entries carry 28-bit triangle positions and node slots
     if (m + 1 >= (1ull << 28) || n >= (1ull << 28)) return fail(RTX_ERR_UNSUPPORTED, "more than 2^28 triangles or BVH nodes");
     // the kernel packs the light index of a shadow query into 16 bits
@@ -545,6 +581,8 @@ int rtx_scene_create(const rtx_scene_desc *desc, rtx_scene **out) {
 }
 
 double rtx_scene_build_seconds(const rtx_scene *sc) { return sc ? sc->build_seconds : 0.0; }
+uint64_t rtx_scene_bvh_nodes(const rtx_scene *sc) { return sc && sc->dev.n_nodes ? sc->dev.n_nodes - 1 : 0; }
+int32_t rtx_scene_bvh_depth(const rtx_scene *sc) { return sc ? sc->dev.bvh_depth : -1; }
 
 void rtx_scene_destroy(rtx_scene *sc) {
     if (!sc) return;

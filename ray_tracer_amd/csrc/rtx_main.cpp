@@ -13,7 +13,8 @@
 #include "rtx.h"
 
 int main(int argc, char **argv) {
-    std::string scene = "teapot", obj, out = "out/canvas.ppm", mode = "reference";
+    std::string scene = "teapot", obj, out = "out/canvas.ppm", mode = "reference", builder = "device";
+    bool tolerant = false;
     int width = 1920, height = 1920, depth = 3, spp = 1, repeats = 3, device = -1;
     unsigned long long standin = 0;
     for (int i = 1; i < argc; i++) {
@@ -30,22 +31,32 @@ int main(int argc, char **argv) {
         else if (a == "--repeats") repeats = atoi(val());
         else if (a == "--device") device = atoi(val());
         else if (a == "--standin") standin = strtoull(val(), nullptr, 10);
+        else if (a == "--builder") builder = val();
+        else if (a == "--tolerant") tolerant = true;
         else {
             fprintf(stderr,
                     "usage: %s [--scene teapot|bunny|erato|dragon|aurelius] [--obj FILE | --standin NTRIS] [--width W] "
-                    "[--height H] [--depth D] [--spp N] [--mode reference|pruned] [--repeats N] [--device K] [--out FILE]\n",
+                    "[--height H] [--depth D] [--spp N] [--mode reference|pruned] [--builder device|host] [--tolerant] [--repeats N] "
+                    "[--device K] [--out FILE]\n",
                     argv[0]);
             return 2;
         }
     }
     if (obj.empty() && !standin) obj = "scenes/" + scene + ".obj";     // scene.hpp:262
 
+    // With the device builder the host scene carries no tree: it is built, and stays, on the GPU.
+    const bool on_device = builder != "host";
+    const uint32_t flags = RTX_LOAD_VERBOSE | (on_device ? RTX_LOAD_NO_BVH : 0) | (tolerant ? RTX_LOAD_TOLERANT : 0);
     rtx_host_scene *hs = nullptr;
-    int rc = standin ? rtx_host_scene_standin(scene.c_str(), standin, 0, nullptr, 1, &hs)
-                     : rtx_host_scene_load_obj(obj.c_str(), scene.c_str(), 1, &hs);
+    int rc = standin ? rtx_host_scene_standin_ex(scene.c_str(), standin, 0, nullptr, flags, device, &hs)
+                     : rtx_host_scene_load_obj_ex(obj.c_str(), scene.c_str(), flags, device, &hs);
     if (rc != RTX_OK) { fprintf(stderr, "%s", rtx_last_error()); return -1; }
     rtx_scene *sc = nullptr;
     if (rtx_scene_create_from_host(hs, device, &sc) != RTX_OK) { fprintf(stderr, "%s\n", rtx_last_error()); return -1; }
+    if (on_device) {                                                    // Scene::Scene prints this (scene.hpp:49-51)
+        const double s = rtx_scene_build_seconds(sc);
+        printf("[ BVH ] %g seconds.\n", (double)(long long)(s * 1000.0) / 1000.0);
+    }
 
     rtx_render_params p;
     rtx_render_params_default(&p, width, height);

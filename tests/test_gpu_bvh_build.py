@@ -120,3 +120,23 @@ def test_scene_built_on_device_with_given_normals_and_host_builder_choice():
         f = sc.render(128, 128, traversal=rt.TRAVERSAL_REFERENCE)
         assert np.array_equal(f.hit, ref.hit)
         assert np.array_equal(f.rgb, ref.rgb)
+
+
+def test_host_scene_without_a_tree_is_built_on_the_device_at_create():
+    with_tree = rt.HostScene.standin("bunny", 20010, seed=3)
+    without = rt.HostScene.standin("bunny", 20010, seed=3, no_bvh=True)
+    assert without.n_nodes == 0 and with_tree.n_nodes > 0
+    a, b = rt.Scene(with_tree), rt.Scene(without)
+    assert b.bvh_nodes == with_tree.n_nodes and b.bvh_depth == with_tree.bvh_depth
+    assert a.build_seconds == 0 and b.build_seconds > 0
+    fa = a.render(192, 108, traversal=rt.TRAVERSAL_REFERENCE, want_stats=True)
+    fb = b.render(192, 108, traversal=rt.TRAVERSAL_REFERENCE, want_stats=True)
+    assert np.array_equal(fa.hit, fb.hit) and np.array_equal(fa.rgb, fb.rgb)
+    assert fa.stats.as_dict()["node_visits"] == fb.stats.as_dict()["node_visits"]
+
+
+def test_loader_with_device_bvh_returns_the_host_builders_arrays():
+    path = os.path.join(HERE, "golden", "teapot.obj")
+    a = rt.HostScene.load_obj(path, "teapot").arrays()
+    b = rt.HostScene.load_obj(path, "teapot", device_bvh=True).arrays()
+    assert a["nodes"].tobytes() == b["nodes"].tobytes() and np.array_equal(a["indices"], b["indices"])

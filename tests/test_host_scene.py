@@ -137,3 +137,55 @@ def test_save_ppm_format(tmp_path):
     p = tmp_path / "c.ppm"
     rt.save_ppm(str(p), rgb)
     assert p.read_bytes() == b"P6\n7 5 255\n" + rgb.tobytes()       # src/main.cpp:103
+
+
+def test_tolerant_loader_reads_what_denormalize_plus_the_reference_loader_read(tmp_path):
+    """A general OBJ (vt/vn groups, negative indices, comments, CRLF, a polygon, trailing newlines)
+    against the same mesh rewritten the way tools/denormalize.py:1-36 does and read by the strict loader."""
+    rng = np.random.default_rng(5)
+    nv, nf = 40, 60
+    v = rng.normal(size=(nv, 3)).round(4)
+    faces = rng.integers(1, nv + 1, size=(nf, 3))
+    lines = ["# a comment", "mtllib x.mtl", "o thing"]
+    lines += [f"v {a:.4f} {b:.4f} {c:.4f}" for a, b, c in v]
+    lines += ["vn 0 0 1", "vt 0.5 0.5", "s off", "usemtl m"]
+    plain = []
+    for k, (a, b, c) in enumerate(faces):
+        style = k % 5
+        if style == 0: lines.append(f"f {a} {b} {c}")
+        elif style == 1: lines.append(f"f {a}/1 {b}/1 {c}/1")
+        elif style == 2: lines.append(f"f {a}//1 {b}//1 {c}//1")
+        elif style == 3: lines.append(f"f {a}/1/1 {b}/1/1 {c}/1/1 {a}/1/1")           # polygon: first three count
+        else: lines.append(f"f {a - nv - 9} {b - nv - 9} {c - nv - 9}")    # negative = from the end of ALL nv + 8 vertices
+        plain.append(f"f {a} {b} {c}")
+    box = [f"v {x} {y} {z}" for x in (-9, 9) for y in (-9, 9) for z in (-9, 9)]
+    lines += box
+    boxf = [(nv + 1, nv + 2, nv + 3)] * 10
+    lines += [f"f {a} {b} {c}" for a, b, c in boxf]
+    general = tmp_path / "general.obj"
+    general.write_bytes(("\r\n".join(lines) + "\r\n\r\n").encode())
+    strict = tmp_path / "strict.obj"
+    strict.write_text("\n".join([f"v {a:.4f} {b:.4f} {c:.4f}" for a, b, c in v] + box + plain +
+                                [f"f {a} {b} {c}" for a, b, c in boxf]))          # no trailing newline
+    a = rt.HostScene.load_obj(str(general), "teapot", tolerant=True).arrays()
+    b = rt.HostScene.load_obj(str(strict), "teapot").arrays()
+    assert a["vertices"].shape == (nf + 10, 9)
+    assert a["vertices"].tobytes() == b["vertices"].tobytes()
+    assert a["nodes"].tobytes() == b["nodes"].tobytes()
+
+
+def test_tolerant_loader_on_the_teapot_equals_the_strict_one():
+    path = os.path.join(os.path.dirname(__file__), "golden", "teapot.obj")
+    a = rt.HostScene.load_obj(path, "teapot", tolerant=True).arrays()
+    b = rt.HostScene.load_obj(path, "teapot").arrays()
+    assert a["vertices"].shape[0] == 6330
+    assert a["vertices"].tobytes() == b["vertices"].tobytes() and np.array_equal(a["indices"], b["indices"])
+
+
+def test_tolerant_loader_errors(tmp_path):
+    bad = tmp_path / "bad.obj"
+    bad.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 9\n")
+    with pytest.raises(rt.RtxError, match="does not exist"):
+        rt.HostScene.load_obj(str(bad), "teapot", tolerant=True)
+    with pytest.raises(rt.RtxError, match="Failed to open file"):
+        rt.HostScene.load_obj(str(tmp_path / "missing.obj"), "teapot", tolerant=True)
