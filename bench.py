@@ -66,6 +66,9 @@ def main():
     ap.add_argument("--spp", type=int, default=1)
     ap.add_argument("--mode", choices=["reference", "pruned"], default="pruned")
     ap.add_argument("--tile", type=int, default=32)
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="frames in flight: step i runs on stream i %% INFLIGHT, so the end of a frame (lanes running dry) "
+                         "overlaps the start of the next one; 1 = every frame waits for the previous one")
     ap.add_argument("--obj", default=None, help="real .obj for the scene (default: the seeded stand-in mesh)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -140,10 +143,14 @@ def main():
                             layout=rt.LAYOUT_PACKED_TILES if packed else rt.LAYOUT_ROW_MAJOR)
     import ctypes as C
     px = int(rt.lib().rtx_output_pixels(C.byref(params)))
-    buf = torch.zeros(px * 3, dtype=torch.uint8, device=dev)
-    frame = torch.zeros(H * W * 3, dtype=torch.uint8, device=dev)
-    gathered = torch.zeros(world * px * 3, dtype=torch.uint8, device=dev) if packed else None
-    stream = torch.cuda.current_stream().cuda_stream
+    F = max(1, min(4, args.inflight))
+    # one set of buffers and one stream per frame in flight
+    bufs = [torch.zeros(px * 3, dtype=torch.uint8, device=dev) for _ in range(F)]
+    frames = [torch.zeros(H * W * 3, dtype=torch.uint8, device=dev) for _ in range(F)]
+    gathers = [torch.zeros(world * px * 3, dtype=torch.uint8, device=dev) if packed else None for _ in range(F)]
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(F - 1)]
+    buf, frame = bufs[0], frames[0]
+    stream = streams[0].cuda_stream
 
     def census(traversal):
         """Untimed pre-pass with the counting kernel: rays and canonical work of this rank's tiles."""
@@ -167,25 +174,31 @@ def main():
 
     out_ptr = frame.data_ptr() if not packed else buf.data_ptr()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # device-side start/end of every timed launch (100 MHz ticks), written by the kernel itself
+    ticks = torch.zeros(max(1, args.steps) * 2, dtype=torch.int64, device=dev)
 
-    def step(i=None):
-        if i is not None:
-            ev[i][0].record()
-        scene.render_device(params, rgb_u8=out_ptr, stream=stream)
-        if i is not None:
-            ev[i][1].record()
-        if packed:
-            all_gather(gathered, buf)
-            rt.untile(params, world, gathered.data_ptr(), frame.data_ptr(), 3, stream)
+    def step(k, i=None):
+        """Frame number k: render (+ all-gather and re-assembly) on stream k % F."""
+        slot = k % F
+        with torch.cuda.stream(streams[slot]):
+            if i is not None:
+                ev[i][0].record()
+            scene.render_device(params, rgb_u8=(frames[slot] if not packed else bufs[slot]).data_ptr(),
+                                ticks=ticks[2 * i:].data_ptr() if i is not None else 0, stream=streams[slot].cuda_stream)
+            if i is not None:
+                ev[i][1].record()
+            if packed:
+                all_gather(gathers[slot], bufs[slot])
+                rt.untile(params, world, gathers[slot].data_ptr(), frames[slot].data_ptr(), 3, streams[slot].cuda_stream)
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        step(args.warmup + i, i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -194,11 +207,13 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+    event_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+    tk = ticks.cpu().numpy().astype("uint64").reshape(-1, 2)
+    kernel_ms = float(((tk[:, 1] - tk[:, 0]).astype("float64") * 1e-5).mean())      # 100 MHz ticks -> ms
     frame_crc = None
     if rank == 0:
         import zlib
-        frame_crc = "%08x" % zlib.crc32(frame.cpu().numpy().tobytes())
+        frame_crc = "%08x" % zlib.crc32(frames[(args.warmup + args.steps - 1) % F].cpu().numpy().tobytes())
 
     # a second, short measurement of the other traversal mode (reported, never the headline)
     other_mode = rt.TRAVERSAL_REFERENCE if mode == rt.TRAVERSAL_PRUNED else rt.TRAVERSAL_PRUNED
@@ -252,6 +267,7 @@ def main():
             "scene_create_seconds": round(create_s, 4),
             "bvh_build_kernels_ms": round(scene.build_seconds * 1e3, 3),
             "frame_crc32": frame_crc,
+            "frames_in_flight": F,
         },
         "roofline": {
             "bound": "hbm",
@@ -263,8 +279,18 @@ def main():
             "traffic_source": traffic["source"] if traffic else None,
             "kernel": "render_kernel",
             "kernel_ms": round(kernel_ms, 4),
+            "kernel_ms_by_stream_events": round(event_ms, 4),
+            "launches_in_flight": F,
+            # all launches in flight together: algorithmic bytes per frame / time per frame
+            "aggregate_achieved": round(launch_alg_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+            "aggregate_frac": round(launch_alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "algorithmic_bytes_per_ray": round(bytes_per_ray, 1),
-            "note": "algorithmic bytes = reference-traversal node visits x 64 B + triangle tests x 96 B "
+            "note": "kernel_ms is the average duration of a launch in the timed region, first block start to last "
+                    "block end on the device clock (what a kernel trace reports; HIP events on the stream also count "
+                    "the wait for the chip while earlier frames drain: kernel_ms_by_stream_events). With "
+                    "launches_in_flight > 1 that many launches share the chip for that long, so achieved/frac are per "
+                    "launch and aggregate_* is their sum (bench.py --inflight 1 gives the kernel with the chip to itself). "
+                    "Algorithmic bytes = reference-traversal node visits x 64 B + triangle tests x 96 B "
                     "(counted on this frame by the counting kernel in reference mode). The pruned traversal "
                     "returns the same pixels while visiting fewer nodes, so frac can exceed 1; other_mode "
                     "gives the same arithmetic for the kernel that does exactly the canonical visits. "

@@ -11,8 +11,10 @@
  * the calling thread.  (The reference throws string literals that main() prints
  * and turns into exit code -1, src/main.cpp:27-32,65-70.)
  *
- * Threading: a scene handle may be used from any thread, one render at a time per
- * handle.  All calls are synchronous unless a stream is passed.
+ * Threading: a scene handle may be used from any thread.  rtx_render() serialises per
+ * handle; rtx_render_device() launches may be in flight on several streams at once (up to
+ * four frames of one scene overlap, a fifth waits for the first).  All calls are
+ * synchronous unless a stream is passed.
  */
 #ifndef RTX_H
 #define RTX_H
@@ -239,6 +241,13 @@ int rtx_render(rtx_scene *scene, const rtx_render_params *p, uint8_t *rgb_out, i
  * before kernel_ms) that the kernel adds into. */
 int rtx_render_device(rtx_scene *scene, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id,
                       void *d_rgb_i32, void *d_t, void *d_stats, void *stream);
+
+/* The same launch, which also leaves its own duration on the device: d_ticks (nullable)
+ * points to two uint64 that receive the start of the first and the end of the last block of
+ * the render kernel on the device's 100 MHz clock.  With several frames in flight, events on
+ * a stream also count the wait for the chip; this does not.  No counterpart in the reference. */
+int rtx_render_device_timed(rtx_scene *scene, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id,
+                            void *d_rgb_i32, void *d_t, void *d_stats, void *d_ticks, void *stream);
 
 /* After an all-gather of `n_ranks` packed tile buffers ([rank][local tile][tile_h][tile_w][3]),
  * writes the row-major frame.  Device pointers; asynchronous on `stream`.

@@ -102,7 +102,8 @@ EXPORTS = (
     "rtx_host_scene_load_obj", "rtx_host_scene_standin", "rtx_host_scene_from_desc", "rtx_host_scene_desc",
     "rtx_host_scene_bvh_depth", "rtx_host_scene_set_camera", "rtx_host_scene_set_lights", "rtx_host_scene_free",
     "rtx_scene_create", "rtx_scene_create_from_host", "rtx_scene_destroy", "rtx_scene_device_bytes",
-    "rtx_render_params_default", "rtx_output_pixels", "rtx_render", "rtx_render_device", "rtx_untile",
+    "rtx_render_params_default", "rtx_output_pixels", "rtx_render", "rtx_render_device", "rtx_render_device_timed",
+    "rtx_untile",
     "rtx_save_ppm", "rtx_selftest_division", "rtx_last_error", "rtx_version",
     "rtx_host_scene_load_obj_ex", "rtx_host_scene_standin_ex",
     "rtx_bvh_build", "rtx_host_scene_rebuild_bvh", "rtx_scene_create_with_builder", "rtx_scene_build_seconds",
@@ -162,6 +163,7 @@ def lib() -> C.CDLL:
     L.rtx_output_pixels.restype = C.c_uint64
     L.rtx_render.argtypes = [vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]
     L.rtx_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, vp, vp, vp]
+    L.rtx_render_device_timed.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, vp, vp, vp, vp]
     L.rtx_untile.argtypes = [C.POINTER(RenderParams), C.c_int32, vp, vp, C.c_int32, vp]
     L.rtx_save_ppm.argtypes = [C.c_char_p, C.c_int32, C.c_int32, vp]
     L.rtx_selftest_division.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
@@ -407,10 +409,11 @@ class Scene:
                 hit = hit.reshape(height, width)
         return Frame(rgb, hit, st)
 
-    def render_device(self, params: RenderParams, *, rgb_u8=0, hit=0, rgb_i32=0, t=0, stats=0, stream=0) -> None:
-        """Asynchronous frame into device pointers (ints, e.g. torch.Tensor.data_ptr())."""
-        _check(lib().rtx_render_device(self._h, C.byref(params), rgb_u8 or None, hit or None, rgb_i32 or None, t or None,
-                                       stats or None, stream or None))
+    def render_device(self, params: RenderParams, *, rgb_u8=0, hit=0, rgb_i32=0, t=0, stats=0, ticks=0, stream=0) -> None:
+        """Asynchronous frame into device pointers (ints, e.g. torch.Tensor.data_ptr()).  ticks: two uint64 that
+        receive the kernel's first-block start and last-block end on the device's 100 MHz clock."""
+        _check(lib().rtx_render_device_timed(self._h, C.byref(params), rgb_u8 or None, hit or None, rgb_i32 or None,
+                                             t or None, stats or None, ticks or None, stream or None))
 
     def close(self) -> None:
         if self._h:

@@ -30,9 +30,16 @@ struct rtx_scene {
     int device = 0;
     rtx::DevScene dev{};
     void *d_nodes = nullptr, *d_tris = nullptr, *d_mats = nullptr, *d_lights = nullptr;
-    // per-lane scratch of the render kernel, kept between frames and grown on demand
-    void *d_scratch = nullptr;
-    uint64_t scratch_bytes = 0;
+    // Per-lane scratch of the render kernel, kept between frames and grown on demand.  kSlots
+    // copies, used in turn, let that many frames be in flight on different streams (the end of a
+    // frame, when lanes run dry, then overlaps the start of the next one); slot_done[k] orders a
+    // launch behind the previous user of its slot.
+    static constexpr int kSlots = 4;
+    void *d_scratch[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t scratch_bytes[kSlots] = {0, 0, 0, 0};
+    hipEvent_t slot_done[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t next_slot = 0;
+    std::mutex slot_lock;
     // work-queue layout of the last launch geometry (see build_tile_order)
     void *d_order = nullptr;
     uint64_t order_capacity = 0;
@@ -591,7 +598,10 @@ void rtx_scene_destroy(rtx_scene *sc) {
     (void)hipFree(sc->d_tris);
     (void)hipFree(sc->d_mats);
     (void)hipFree(sc->d_lights);
-    (void)hipFree(sc->d_scratch);
+    for (int k = 0; k < rtx_scene::kSlots; k++) {
+        (void)hipFree(sc->d_scratch[k]);
+        if (sc->slot_done[k]) (void)hipEventDestroy(sc->slot_done[k]);
+    }
     (void)hipFree(sc->d_order);
     delete sc;
 }
@@ -622,6 +632,11 @@ uint64_t rtx_output_pixels(const rtx_render_params *p) {
 
 int rtx_render_device(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id, void *d_rgb_i32, void *d_t,
                       void *d_stats, void *stream) {
+    return rtx_render_device_timed(sc, p, d_rgb_u8, d_hit_id, d_rgb_i32, d_t, d_stats, nullptr, stream);
+}
+
+int rtx_render_device_timed(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id, void *d_rgb_i32, void *d_t,
+                            void *d_stats, void *d_ticks, void *stream) {
     if (!sc) return fail(RTX_ERR_INVALID, "scene is NULL");
     ResolvedParams rp;
     if (int rc = resolve_params(p, &rp)) return rc;
@@ -635,6 +650,7 @@ int rtx_render_device(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8,
     r.rgb_i32 = (int32_t *)d_rgb_i32;
     r.t = (double *)d_t;
     r.stats = (unsigned long long *)d_stats;
+    r.ticks = (unsigned long long *)d_ticks;
     // LDS stack: the largest block whose stack fits 64 KiB
     uint32_t block = 256;
     while (block > 64 && rtx::render_lds_bytes(sc->dev.bvh_depth, block) > 65536) block >>= 1;
@@ -661,20 +677,28 @@ int rtx_render_device(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8,
     uint64_t grid_blocks = (total_blocks + wpb - 1) / wpb;
     if (grid_blocks > resident) grid_blocks = resident;
     // Scratch: a work counter, then (4 + depth) doubles and (1 + 3*depth) ints per resident lane.
-    // The buffer belongs to the scene handle (one render in flight per handle) and only grows.
+    // The buffers belong to the scene handle and only grow.
+    std::lock_guard<std::mutex> hold_slots(sc->slot_lock);
+    const int slot = (int)(sc->next_slot++ % rtx_scene::kSlots);
     {
         const uint64_t lanes = grid_blocks * block;
         const uint64_t need = rtx::render_scratch_bytes(lanes, r.depth);
-        if (need > sc->scratch_bytes) {
-            if (sc->d_scratch) HIP_TRY(hipFree(sc->d_scratch));       // waits for launches still using it
-            sc->d_scratch = nullptr;
-            sc->scratch_bytes = 0;
-            HIP_TRY(hipMalloc(&sc->d_scratch, need));
-            sc->scratch_bytes = need;
+        if (!sc->slot_done[slot]) HIP_TRY(hipEventCreateWithFlags(&sc->slot_done[slot], hipEventDisableTiming));
+        else HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, sc->slot_done[slot], 0));   // the slot's previous frame
+        if (need > sc->scratch_bytes[slot]) {
+            // grow every slot now: an allocation stalls the device, better once than once per slot
+            for (int k = 0; k < rtx_scene::kSlots; k++) {
+                if (need <= sc->scratch_bytes[k]) continue;
+                if (sc->d_scratch[k]) HIP_TRY(hipFree(sc->d_scratch[k]));         // waits for launches still using it
+                sc->d_scratch[k] = nullptr;
+                sc->scratch_bytes[k] = 0;
+                HIP_TRY(hipMalloc(&sc->d_scratch[k], need));
+                sc->scratch_bytes[k] = need;
+            }
         }
-        r.work = (uint32_t *)sc->d_scratch;
+        r.work = (uint32_t *)sc->d_scratch[slot];
         r.scratch_lanes = lanes;
-        r.scratch_f64 = (double *)((char *)sc->d_scratch + 1024);
+        r.scratch_f64 = (double *)((char *)sc->d_scratch[slot] + 1024);
         r.scratch_i32 = (int32_t *)((char *)r.scratch_f64 + lanes * (4 + (uint64_t)r.depth) * 8);
         HIP_TRY(hipMemsetAsync(r.work, 0, 1024, (hipStream_t)stream));
     }
@@ -715,8 +739,8 @@ int rtx_render_device(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8,
                 HIP_TRY(hipMalloc(&sc->d_order, bytes));
                 sc->order_capacity = bytes;
             }
-            // earlier launches may still be reading the previous layout
-            HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+            // earlier launches, on any stream, may still be reading the previous layout
+            HIP_TRY(hipDeviceSynchronize());
             HIP_TRY(hipMemcpy(sc->d_order, order.data(), bytes, hipMemcpyHostToDevice));
             sc->order_key = key;
         }
@@ -735,8 +759,13 @@ int rtx_render_device(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8,
         HIP_TRY(hipMemset(d_log, 0, n_waves * 16));
         r.wave_log = d_log;
     }
+    if (d_ticks) {
+        HIP_TRY(hipMemsetAsync(d_ticks, 0xff, 8, (hipStream_t)stream));
+        HIP_TRY(hipMemsetAsync((char *)d_ticks + 8, 0x00, 8, (hipStream_t)stream));
+    }
     HIP_TRY(rtx::launch_render(sc->dev, r, p->traversal == RTX_TRAVERSAL_PRUNED, d_stats != nullptr, block, (uint32_t)grid_blocks,
                                (hipStream_t)stream));
+    HIP_TRY(hipEventRecord(sc->slot_done[slot], (hipStream_t)stream));
     if (d_log) {
         std::vector<unsigned long long> h(n_waves * 2);
         HIP_TRY(hipMemcpy(h.data(), d_log, n_waves * 16, hipMemcpyDeviceToHost));

@@ -609,7 +609,7 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t waves_per_block = blockDim.x >> 6;
     const uint64_t gw = (uint64_t)blockIdx.x * waves_per_block + wave;   // resident wave slot
-    const unsigned long long wave_t0 = rp.wave_log ? wall_clock64() : 0;
+    const unsigned long long wave_t0 = (rp.wave_log || rp.ticks) ? wall_clock64() : 0;
 
     const uint32_t stride = rp.stack_stride;
     uint32_t *stack = lds + threadIdx.x;
@@ -661,11 +661,11 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
             if (L.state == ST_INNER) inner_step<PRUNE, STATS>(L, sc, stack, stride, c);
         }
         if (pick_leaf || (all_kinds && n_leaf)) {
-            if (STATS && lane == 0) { rounds[1]++; lane_steps[1] += __popcll(__ballot(L.state == ST_LEAF)); }
+            if (STATS) { const int k = __popcll(__ballot(L.state == ST_LEAF)); if (lane == 0) { rounds[1]++; lane_steps[1] += k; } }
             if (L.state == ST_LEAF) leaf_step<PRUNE, STATS>(L, sc, stack, stride, c);
         }
         if ((!pick_inner && !pick_leaf) || (all_kinds && n_shade)) {
-            if (STATS && lane == 0) { rounds[2]++; lane_steps[2] += __popcll(__ballot(L.state == ST_SHADE)); }
+            if (STATS) { const int k = __popcll(__ballot(L.state == ST_SHADE)); if (lane == 0) { rounds[2]++; lane_steps[2] += k; } }
             if (L.state == ST_SHADE) shade_step<PRUNE, STATS>(L, acc, sc, rp, scr, c);
             // hand pixels to the lanes without one, in lane order
             unsigned long long need = __ballot(L.state == ST_FETCH);
@@ -733,6 +733,11 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
     if (rp.wave_log && lane == 0) {
         rp.wave_log[2 * gw] = wave_t0;
         rp.wave_log[2 * gw + 1] = wall_clock64();
+    }
+    // first wave start / last wave end of the launch, one pair of atomics per block
+    if (rp.ticks && threadIdx.x == 0) {
+        atomicMin(&rp.ticks[0], wave_t0);
+        atomicMax(&rp.ticks[1], (unsigned long long)wall_clock64());
     }
 }
 
