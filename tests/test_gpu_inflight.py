@@ -1,0 +1,42 @@
+"""Several frames of one scene in flight on different streams: each must equal the frame rendered alone."""
+import os
+
+import numpy as np
+import pytest
+
+import ray_tracer_amd as rt
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_overlapping_frames_equal_frames_rendered_alone():
+    import torch
+    hs = rt.HostScene.load_obj(os.path.join(HERE, "golden", "teapot.obj"), "teapot", no_bvh=True)
+    scene = rt.Scene(hs)
+    W, H = 640, 400
+    jobs = [dict(traversal=rt.TRAVERSAL_PRUNED), dict(traversal=rt.TRAVERSAL_REFERENCE), dict(traversal=rt.TRAVERSAL_PRUNED, depth=1),
+            dict(traversal=rt.TRAVERSAL_PRUNED, window=(100, 500, 50, 300)), dict(traversal=rt.TRAVERSAL_PRUNED, spp=2, seed=7),
+            dict(traversal=rt.TRAVERSAL_REFERENCE, depth=0), dict(traversal=rt.TRAVERSAL_PRUNED)]
+    alone = []
+    for kw in jobs:
+        buf = torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda")
+        scene.render_device(rt.make_params(W, H, **kw), rgb_u8=buf.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        alone.append(buf.cpu().numpy())
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    bufs = [torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda") for _ in jobs]
+    ticks = torch.zeros(2 * len(jobs), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    for rep in range(3):                       # more launches than scratch slots
+        for k, kw in enumerate(jobs):
+            s = streams[k % 3]
+            with torch.cuda.stream(s):
+                bufs[k].zero_()
+                scene.render_device(rt.make_params(W, H, **kw), rgb_u8=bufs[k].data_ptr(), ticks=ticks[2 * k:].data_ptr(),
+                                    stream=s.cuda_stream)
+        torch.cuda.synchronize()
+        for k in range(len(jobs)):
+            assert np.array_equal(bufs[k].cpu().numpy(), alone[k]), (rep, k)
+    t = ticks.cpu().numpy().reshape(-1, 2)
+    assert (t[:, 1] > t[:, 0]).all()           # every launch left its start and end on the device clock
