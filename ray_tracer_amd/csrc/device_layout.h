@@ -97,6 +97,7 @@ struct DevRender {
     uint32_t total_blocks;     // 8x8 blocks of this launch
     int32_t w_inner, w_leaf, w_shade;   // weights of the wave's step choice
     int32_t tail_lanes;                 // at most this many live lanes: run every kind of step each round
+    int32_t also_lanes;                 // a kind with at least this many waiting lanes runs in every round
     unsigned long long *wave_log;       // diagnostics: {start, end} 100 MHz ticks per wave, or NULL
     unsigned long long *ticks;          // {earliest block start, latest block end} in 100 MHz ticks, or NULL
 };

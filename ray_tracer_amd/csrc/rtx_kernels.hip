@@ -656,15 +656,15 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
         const bool all_kinds = n_inner + n_leaf + n_shade <= rp.tail_lanes;
         const bool pick_inner = w_inner >= w_leaf && w_inner >= w_shade;
         const bool pick_leaf = !pick_inner && w_leaf >= w_shade;
-        if (pick_inner || (all_kinds && n_inner)) {
+        if (pick_inner || (all_kinds && n_inner) || n_inner >= rp.also_lanes) {
             if (STATS && lane == 0) { rounds[0]++; lane_steps[0] += n_inner; }
             if (L.state == ST_INNER) inner_step<PRUNE, STATS>(L, sc, stack, stride, c);
         }
-        if (pick_leaf || (all_kinds && n_leaf)) {
+        if (pick_leaf || (all_kinds && n_leaf) || n_leaf >= rp.also_lanes) {
             if (STATS) { const int k = __popcll(__ballot(L.state == ST_LEAF)); if (lane == 0) { rounds[1]++; lane_steps[1] += k; } }
             if (L.state == ST_LEAF) leaf_step<PRUNE, STATS>(L, sc, stack, stride, c);
         }
-        if ((!pick_inner && !pick_leaf) || (all_kinds && n_shade)) {
+        if ((!pick_inner && !pick_leaf) || (all_kinds && n_shade) || n_shade >= rp.also_lanes) {
             if (STATS) { const int k = __popcll(__ballot(L.state == ST_SHADE)); if (lane == 0) { rounds[2]++; lane_steps[2] += k; } }
             if (L.state == ST_SHADE) shade_step<PRUNE, STATS>(L, acc, sc, rp, scr, c);
             // hand pixels to the lanes without one, in lane order

@@ -53,3 +53,7 @@ if "tail" in exps:
 if "tile" in exps:
     for t in (8, 16, 32, 64):
         run(f"tile={t}", {}, tile=(t, t))
+if "also" in exps:
+    for t in (65, 48, 40, 32, 24, 16, 8):
+        run(f"also_lanes={t}", {"RTX_ALSO_LANES": t})
+    os.environ["RTX_ALSO_LANES"] = "65"
