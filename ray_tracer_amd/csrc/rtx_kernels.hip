@@ -603,7 +603,20 @@ __device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScen
 }
 
 template <bool PRUNE, bool STATS>
-__global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const DevScene sc, const DevRender rp) {
+__global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const DevScene sc_arg, const DevRender rp_arg) {
+    // The two argument blocks hold ~100 dwords.  Read as ordinary kernel arguments they are all
+    // loaded into scalar registers up front and most of them spilled again; read through the
+    // kernel-argument pointer, with its origin hidden from the optimiser, each field is loaded
+    // where it is used (the fields the traversal steps use stay in registers, the rest cost one
+    // scalar load in the shading step).
+    (void)sc_arg;
+    (void)rp_arg;
+    typedef const char __attribute__((address_space(4))) *KernArgs;
+    KernArgs ka = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    constexpr size_t rp_offset = (sizeof(DevScene) + alignof(DevRender) - 1) / alignof(DevRender) * alignof(DevRender);
+    const DevScene &sc = *(const DevScene *)(ka);
+    const DevRender &rp = *(const DevRender *)(ka + rp_offset);
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
