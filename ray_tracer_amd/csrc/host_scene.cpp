@@ -2,6 +2,8 @@
 // Citations are file:line in khaganmv/ray-tracer.
 #include "host_scene.hpp"
 
+#include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <chrono>
 #include <cmath>
@@ -9,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <thread>
 
 namespace rtx {
 
@@ -29,6 +32,31 @@ bool slurp(const std::string &path, std::string *out) {
     return got == static_cast<size_t>(sz);
 }
 
+// Threads for the host-side loops: OMP_NUM_THREADS when set (GPU boxes export their CPU share
+// there), else the hardware's count, never more than 16.
+size_t worker_threads() {
+    size_t n = std::thread::hardware_concurrency();
+    if (const char *v = getenv("OMP_NUM_THREADS")) {
+        const long k = atol(v);
+        if (k > 0) n = static_cast<size_t>(k);
+    }
+    return std::max<size_t>(1, std::min<size_t>(n, 16));
+}
+
+template <typename F>
+void parallel_for(size_t n_items, F fn) {
+    const size_t n_threads = std::min(worker_threads(), n_items);
+    if (n_threads <= 1) {
+        for (size_t i = 0; i < n_items; i++) fn(i);
+        return;
+    }
+    std::vector<std::thread> pool;
+    std::atomic<size_t> next{0};
+    for (size_t t = 0; t < n_threads; t++)
+        pool.emplace_back([&]() { for (size_t i = next++; i < n_items; i = next++) fn(i); });
+    for (std::thread &t : pool) t.join();
+}
+
 }  // namespace
 
 // Scene::parseOBJ, include/scene.hpp:213-253.
@@ -42,54 +70,168 @@ bool slurp(const std::string &path, std::string *out) {
 // factories address materials relative to the END of the triangle list.
 // A 'v' or 'f' followed by something that is not three numbers leaves the
 // reference's stream failed and its loop spinning; here that is an error.
-int parse_obj(const std::string &path, std::vector<double> *vertices9, std::string *err) {
-    std::string text;
-    if (!slurp(path, &text)) { *err = "Failed to open file.\n"; return RTX_ERR_IO; }
-    std::vector<double> pos;               // 3 per vertex
-    vertices9->clear();
-    const char *p = text.c_str();
-    const char *const end = p + text.size();
+//
+// The text is cut into pieces at line starts that open a record ("\nv" / "\nf") and the
+// pieces are tokenised on separate threads with the same grammar; a piece boundary is never
+// inside a record of a file the reference can read (a record's three numbers are followed by
+// the next record's letter).  Faces keep their 1-based indices until every piece's vertex
+// count is known.
+namespace {
+
+struct ObjPiece {
+    std::vector<double> pos;          // 3 per vertex
+    std::vector<long long> faces;     // i j k, then the number of vertices defined before the face in this piece
+    std::string err;
+    int rc = RTX_OK;
+};
+
+void parse_piece(const char *p, const char *const end, bool last_piece, ObjPiece *out) {
     char id = 0;
     double xyz[3] = {0, 0, 0};
     long long ijk[3] = {0, 0, 0};
     for (bool done = false; !done;) {
         while (p < end && isspace(static_cast<unsigned char>(*p))) p++;
-        const bool fresh = p < end;        // false: ran into end-of-file, locals are stale
+        const bool fresh = p < end;        // false: ran into the end, locals are stale
         if (fresh) id = *p++;
-        else done = true;
+        else if (last_piece) done = true;  // end-of-file: the reference's loop body runs once more
+        else break;
         if (id == 'v') {
             if (fresh) {
                 for (double &c : xyz) {
                     char *q = nullptr;
                     c = strtod(p, &q);
-                    if (q == p) { *err = "OBJ: vertex record is not 'v x y z'"; return RTX_ERR_UNSUPPORTED; }
+                    if (q == p || q > end) { out->err = "OBJ: vertex record is not 'v x y z'"; out->rc = RTX_ERR_UNSUPPORTED; return; }
                     p = q;
                 }
-                if (p >= end) done = true; // last number touched end-of-file: eofbit set
+                if (last_piece && p >= end) done = true;   // last number touched end-of-file: eofbit set
             }
-            pos.insert(pos.end(), xyz, xyz + 3);
+            out->pos.insert(out->pos.end(), xyz, xyz + 3);
         } else if (id == 'f') {
             if (fresh) {
                 for (long long &c : ijk) {
                     char *q = nullptr;
                     c = strtoll(p, &q, 10);
-                    if (q == p) { *err = "OBJ: face record is not 'f i j k' (run tools/denormalize first)"; return RTX_ERR_UNSUPPORTED; }
+                    if (q == p || q > end) {
+                        out->err = "OBJ: face record is not 'f i j k' (use the tolerant loader)";
+                        out->rc = RTX_ERR_UNSUPPORTED;
+                        return;
+                    }
                     p = q;
                 }
-                if (p >= end) done = true;
+                if (last_piece && p >= end) done = true;
             }
-            for (long long c : ijk) {
-                // the reference indexes vertices[c - 1] unchecked (scene.hpp:237-239)
-                if (c < 1 || static_cast<uint64_t>(c) * 3 > pos.size()) {
-                    *err = "OBJ: face references a vertex that is not defined yet";
-                    return RTX_ERR_INVALID;
-                }
-                const double *v = &pos[static_cast<size_t>(c - 1) * 3];
-                vertices9->insert(vertices9->end(), v, v + 3);
-            }
+            out->faces.insert(out->faces.end(), ijk, ijk + 3);
+            out->faces.push_back(static_cast<long long>(out->pos.size() / 3));
         }
     }
+}
+
+}  // namespace
+
+namespace {
+
+// Line-based grammar of the tolerant loader for one piece of the text (pieces start at line starts).
+void parse_piece_tolerant(const char *p, const char *const end, ObjPiece *out) {
+    auto record = [&](const char *q, char id) { return q + 1 < end && q[0] == id && (q[1] == ' ' || q[1] == '\t'); };
+    while (p < end) {
+        const char *eol = static_cast<const char *>(memchr(p, '\n', static_cast<size_t>(end - p)));
+        const char *const next = eol ? eol + 1 : end;
+        while (p < next && (*p == ' ' || *p == '\t')) p++;
+        if (record(p, 'v')) {
+            const char *q = p + 1;
+            for (int k = 0; k < 3; k++) {
+                char *r = nullptr;
+                const double c = strtod(q, &r);
+                if (r == q || r > next) { out->err = "OBJ: vertex record is not 'v x y z'"; out->rc = RTX_ERR_UNSUPPORTED; return; }
+                out->pos.push_back(c);
+                q = r;
+            }
+        } else if (record(p, 'f')) {
+            const char *q = p + 1;
+            for (int k = 0; k < 3; k++) {
+                char *r = nullptr;
+                const long long c = strtoll(q, &r, 10);
+                if (r == q || r > next) { out->err = "OBJ: face record has fewer than three vertices"; out->rc = RTX_ERR_UNSUPPORTED; return; }
+                q = r;
+                while (q < next && *q != ' ' && *q != '\t' && *q != '\n' && *q != '\r') q++;   // the /vt/vn part of the group
+                out->faces.push_back(c);
+            }
+            out->faces.push_back(0);
+        }
+        p = next;
+    }
+}
+
+// Tokenises the file in pieces on the worker threads and assembles 9 doubles per face.
+// strict: the reference's grammar and its "vertex must be defined before the face" order;
+// otherwise the tolerant grammar, indices resolved against the whole vertex list.
+int load_obj_text(const std::string &path, bool strict, std::vector<double> *vertices9, std::string *err) {
+    std::string text;
+    if (!slurp(path, &text)) { *err = "Failed to open file.\n"; return RTX_ERR_IO; }
+    vertices9->clear();
+    const char *const begin = text.c_str();
+    const char *const end = begin + text.size();
+    // piece boundaries: a few pieces per thread, at least 256 KiB each
+    const size_t want = std::max<size_t>(1, std::min<size_t>(4 * worker_threads(), text.size() / (1u << 18) + 1));
+    std::vector<const char *> cut{begin};
+    for (size_t k = 1; k < want; k++) {
+        const char *p = begin + text.size() / want * k;
+        if (p <= cut.back()) continue;
+        while (p + 1 < end && !(p[0] == '\n' && (!strict || p[1] == 'v' || p[1] == 'f'))) p++;
+        if (p + 1 >= end) break;
+        cut.push_back(p + 1);
+    }
+    cut.push_back(end);
+    const size_t n_pieces = cut.size() - 1;
+    std::vector<ObjPiece> pieces(n_pieces);
+    parallel_for(n_pieces, [&](size_t k) {
+        if (strict) parse_piece(cut[k], cut[k + 1], k + 1 == n_pieces, &pieces[k]);
+        else parse_piece_tolerant(cut[k], cut[k + 1], &pieces[k]);
+    });
+    for (const ObjPiece &pc : pieces)
+        if (pc.rc != RTX_OK) { *err = pc.err; return pc.rc; }
+    // global vertex list, face offsets
+    std::vector<size_t> v_before(n_pieces + 1, 0), f_before(n_pieces + 1, 0);
+    for (size_t k = 0; k < n_pieces; k++) {
+        v_before[k + 1] = v_before[k] + pieces[k].pos.size() / 3;
+        f_before[k + 1] = f_before[k] + pieces[k].faces.size() / 4;
+    }
+    const long long n_vertices = static_cast<long long>(v_before[n_pieces]);
+    std::vector<double> pos(3 * v_before[n_pieces]);
+    parallel_for(n_pieces, [&](size_t k) {
+        if (!pieces[k].pos.empty()) memcpy(&pos[3 * v_before[k]], pieces[k].pos.data(), pieces[k].pos.size() * sizeof(double));
+    });
+    vertices9->resize(9 * f_before[n_pieces]);
+    std::vector<int> bad(n_pieces, 0);
+    parallel_for(n_pieces, [&](size_t k) {
+        const std::vector<long long> &f = pieces[k].faces;
+        double *out = vertices9->data() + 9 * f_before[k];
+        // strict: the reference indexes vertices[c - 1] unchecked (scene.hpp:237-239); a face may
+        // only use vertices that precede it
+        const long long defined0 = static_cast<long long>(v_before[k]);
+        for (size_t i = 0; i + 3 < f.size(); i += 4, out += 9) {
+            const long long limit = strict ? defined0 + f[i + 3] : n_vertices;
+            for (int c = 0; c < 3; c++) {
+                long long v = f[i + c];
+                if (!strict && v < 0) v = n_vertices + v + 1;       // tools/denormalize.py:26-31
+                if (v < 1 || v > limit) { bad[k] = 1; return; }
+                memcpy(out + 3 * c, &pos[3 * static_cast<size_t>(v - 1)], 3 * sizeof(double));
+            }
+        }
+    });
+    for (int b : bad)
+        if (b) {
+            *err = strict ? "OBJ: face references a vertex that is not defined yet" : "OBJ: face references a vertex that does not exist";
+            return RTX_ERR_INVALID;
+        }
+    if (!strict && vertices9->empty()) { *err = "OBJ: no faces"; return RTX_ERR_INVALID; }
     return RTX_OK;
+}
+
+}  // namespace
+
+int parse_obj(const std::string &path, std::vector<double> *vertices9, std::string *err) {
+    return load_obj_text(path, true, vertices9, err);
 }
 
 // tools/denormalize.py:1-36 + Scene::parseOBJ in one pass over the text.  The script
@@ -97,55 +239,7 @@ int parse_obj(const std::string &path, std::vector<double> *vertices9, std::stri
 // each face as `f i0 i1 i2` from the leading integer of its first three index groups,
 // resolving negative indices against the number of vertices in the whole file.
 int parse_obj_tolerant(const std::string &path, std::vector<double> *vertices9, std::string *err) {
-    std::string text;
-    if (!slurp(path, &text)) { *err = "Failed to open file.\n"; return RTX_ERR_IO; }
-    const char *const begin = text.c_str();
-    const char *const end = begin + text.size();
-    auto next_line = [&](const char *p) {
-        const char *q = static_cast<const char *>(memchr(p, '\n', static_cast<size_t>(end - p)));
-        return q ? q + 1 : end;
-    };
-    auto record = [&](const char *p, char id) {          // "<id><blank>" at the start of a line
-        return p + 1 < end && p[0] == id && (p[1] == ' ' || p[1] == '\t');
-    };
-    std::vector<double> pos;
-    size_t n_faces = 0;
-    for (const char *p = begin; p < end; p = next_line(p)) {
-        while (p < end && (*p == ' ' || *p == '\t')) p++;
-        if (record(p, 'v')) {
-            const char *q = p + 1;
-            for (int k = 0; k < 3; k++) {
-                char *r = nullptr;
-                const double c = strtod(q, &r);
-                if (r == q) { *err = "OBJ: vertex record is not 'v x y z'"; return RTX_ERR_UNSUPPORTED; }
-                pos.push_back(c);
-                q = r;
-            }
-        } else if (record(p, 'f')) {
-            n_faces++;
-        }
-    }
-    const long long n_vertices = static_cast<long long>(pos.size() / 3);
-    vertices9->clear();
-    vertices9->reserve(9 * n_faces);
-    for (const char *p = begin; p < end; p = next_line(p)) {
-        while (p < end && (*p == ' ' || *p == '\t')) p++;
-        if (!record(p, 'f')) continue;
-        const char *q = p + 1;
-        for (int k = 0; k < 3; k++) {
-            char *r = nullptr;
-            long long c = strtoll(q, &r, 10);
-            if (r == q) { *err = "OBJ: face record has fewer than three vertices"; return RTX_ERR_UNSUPPORTED; }
-            q = r;
-            while (q < end && *q != ' ' && *q != '\t' && *q != '\n' && *q != '\r') q++;   // the /vt/vn part of the group
-            if (c < 0) c = n_vertices + c + 1;
-            if (c < 1 || c > n_vertices) { *err = "OBJ: face references a vertex that does not exist"; return RTX_ERR_INVALID; }
-            const double *v = &pos[static_cast<size_t>(c - 1) * 3];
-            vertices9->insert(vertices9->end(), v, v + 3);
-        }
-    }
-    if (vertices9->empty()) { *err = "OBJ: no faces"; return RTX_ERR_INVALID; }
-    return RTX_OK;
+    return load_obj_text(path, false, vertices9, err);
 }
 
 // Triangle::Triangle, include/triangle.hpp:16-25.
@@ -153,7 +247,9 @@ void setup_triangles(HostScene *hs, bool have_normals) {
     const uint64_t n = hs->n_triangles();
     if (!have_normals) hs->normals.resize(3 * n);
     hs->centroids.resize(3 * n);
-    for (uint64_t i = 0; i < n; i++) {
+    const uint64_t per = 1u << 16;
+    parallel_for((n + per - 1) / per, [&](size_t chunk) {
+    for (uint64_t i = chunk * per; i < std::min<uint64_t>(n, (chunk + 1) * per); i++) {
         const double *v = &hs->vertices[9 * i];
         if (!have_normals) {
             double ax = v[3] - v[0], ay = v[4] - v[1], az = v[5] - v[2];      // e01
@@ -166,6 +262,7 @@ void setup_triangles(HostScene *hs, bool have_normals) {
         }
         for (int k = 0; k < 3; k++) hs->centroids[3 * i + k] = ((v[k] + v[3 + k]) + v[6 + k]) / 3;
     }
+    });
 }
 
 // The five factories, include/scene.hpp:255-448: they differ only in the file name
