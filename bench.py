@@ -66,9 +66,10 @@ def main():
     ap.add_argument("--spp", type=int, default=1)
     ap.add_argument("--mode", choices=["reference", "pruned"], default="pruned")
     ap.add_argument("--tile", type=int, default=32)
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=4,
                     help="frames in flight: step i runs on stream i %% INFLIGHT, so the end of a frame (lanes running dry) "
-                         "overlaps the start of the next one; 1 = every frame waits for the previous one")
+                         "overlaps the start of the next one; 1 = every frame waits for the previous one; 4 = one stream "
+                         "per hardware queue of the process")
     ap.add_argument("--obj", default=None, help="real .obj for the scene (default: the seeded stand-in mesh)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -143,7 +144,7 @@ def main():
                             layout=rt.LAYOUT_PACKED_TILES if packed else rt.LAYOUT_ROW_MAJOR)
     import ctypes as C
     px = int(rt.lib().rtx_output_pixels(C.byref(params)))
-    F = max(1, min(4, args.inflight))
+    F = max(1, min(8, args.inflight))
     # one set of buffers and one stream per frame in flight
     bufs = [torch.zeros(px * 3, dtype=torch.uint8, device=dev) for _ in range(F)]
     frames = [torch.zeros(H * W * 3, dtype=torch.uint8, device=dev) for _ in range(F)]

@@ -13,7 +13,7 @@
  *
  * Threading: a scene handle may be used from any thread.  rtx_render() serialises per
  * handle; rtx_render_device() launches may be in flight on several streams at once (up to
- * four frames of one scene overlap, a fifth waits for the first).  All calls are
+ * eight frames of one scene overlap, a ninth waits for the first).  All calls are
  * synchronous unless a stream is passed.
  */
 #ifndef RTX_H

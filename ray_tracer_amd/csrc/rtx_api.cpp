@@ -34,10 +34,10 @@ struct rtx_scene {
     // copies, used in turn, let that many frames be in flight on different streams (the end of a
     // frame, when lanes run dry, then overlaps the start of the next one); slot_done[k] orders a
     // launch behind the previous user of its slot.
-    static constexpr int kSlots = 4;
-    void *d_scratch[kSlots] = {nullptr, nullptr, nullptr, nullptr};
-    uint64_t scratch_bytes[kSlots] = {0, 0, 0, 0};
-    hipEvent_t slot_done[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    static constexpr int kSlots = 8;
+    void *d_scratch[kSlots] = {};
+    uint64_t scratch_bytes[kSlots] = {};
+    hipEvent_t slot_done[kSlots] = {};
     uint32_t next_slot = 0;
     std::mutex slot_lock;
     // work-queue layout of the last launch geometry (see build_tile_order)

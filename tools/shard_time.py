@@ -1,20 +1,26 @@
-import sys, os
+"""Kernel time of one rank's share (tiles k = rank mod world) of a 4K frame on one GPU, with 1 and 3 frames in flight:
+what strong scaling over `world` GPUs can reach before the gather."""
+import os, sys, time
 sys.path.insert(0, os.getcwd())
-import torch, ctypes as C
+import ctypes as C
+import torch
 import ray_tracer_amd as rt
+
 host = rt.HostScene.standin("dragon", seed=0, no_bvh=True)
 dev = rt.Scene(host)
 W, H = 3840, 2160
-stream = torch.cuda.current_stream().cuda_stream
 for world in (1, 2, 4, 8):
-    for tile in (32, 16, 8):
-        p = rt.make_params(W, H, traversal=rt.TRAVERSAL_PRUNED, tile=(tile, tile), tile_rank=0, tile_count=world,
-                           layout=rt.LAYOUT_PACKED_TILES if world > 1 else rt.LAYOUT_ROW_MAJOR)
-        px = int(rt.lib().rtx_output_pixels(C.byref(p)))
-        buf = torch.zeros(px * 3, dtype=torch.uint8, device="cuda")
-        ts = []
-        for _ in range(6):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(); dev.render_device(p, rgb_u8=buf.data_ptr(), stream=stream); b.record(); torch.cuda.synchronize()
-            ts.append(a.elapsed_time(b))
-        print(f"world {world} tile {tile}: rank-0 kernel {min(ts[1:]):.3f} ms  (ideal {4.43/world:.3f})", flush=True)
+    p = rt.make_params(W, H, traversal=rt.TRAVERSAL_PRUNED, tile=(32, 32), tile_rank=0, tile_count=world,
+                       layout=rt.LAYOUT_PACKED_TILES if world > 1 else rt.LAYOUT_ROW_MAJOR)
+    px = int(rt.lib().rtx_output_pixels(C.byref(p)))
+    out = {}
+    for F in (1, 3, 4, 6, 8):
+        streams = [torch.cuda.Stream() for _ in range(F)]
+        bufs = [torch.zeros(px * 3, dtype=torch.uint8, device="cuda") for _ in range(F)]
+        def run(n):
+            for k in range(n):
+                dev.render_device(p, rgb_u8=bufs[k % F].data_ptr(), stream=streams[k % F].cuda_stream)
+            torch.cuda.synchronize()
+        run(6)
+        t0 = time.perf_counter(); run(60); out[F] = (time.perf_counter() - t0) / 60 * 1e3
+    print(f"world {world}: rank-0 share per frame, 1,3,4,6,8 in flight: " + " ".join(f"{out[F]:.3f}" for F in (1, 3, 4, 6, 8)) + " ms", flush=True)
