@@ -140,3 +140,26 @@ def test_loader_with_device_bvh_returns_the_host_builders_arrays():
     a = rt.HostScene.load_obj(path, "teapot").arrays()
     b = rt.HostScene.load_obj(path, "teapot", device_bvh=True).arrays()
     assert a["nodes"].tobytes() == b["nodes"].tobytes() and np.array_equal(a["indices"], b["indices"])
+
+
+@pytest.mark.parametrize("n", [40, 300])
+def test_partition_that_leaves_one_side_empty_still_permutes_the_leaf(n):
+    """Centroids one ulp apart: the chosen plane rounds back onto the smaller centroid, `centroid < plane` holds for
+    no triangle, the reference's partition loop rotates the range by one and the node stays a leaf (bvh.hpp:128-141)."""
+    rng = np.random.default_rng(n)
+    v = np.zeros((n, 3, 3))
+    v[:, :, 0] = 1.0
+    v[:, 0, 1], v[:, 1, 1], v[:, 2, 1] = 0.0, 1.0, 0.0
+    v[:, 0, 2], v[:, 1, 2], v[:, 2, 2] = 0.0, 0.0, 1.0
+    odd = rng.random(n) < 0.5
+    v[odd, 2, 0] = 1.0 + 2.0 ** -51          # centroid x = 1 + 2^-52
+    host, dev = same_tree(v.reshape(n, 9))
+    assert host["nodes"].shape[0] == 1 and not np.array_equal(host["indices"], np.arange(n))
+
+
+def test_many_identical_triangles_make_a_large_leaf():
+    rng = np.random.default_rng(3)
+    v = rng.uniform(-1, 1, size=(500, 9))
+    v[100:400] = v[100]                      # 300 copies: no axis separates them
+    host, _ = same_tree(v)
+    assert host["nodes"]["count"].max() >= 300
