@@ -264,6 +264,13 @@ int rtx_save_ppm(const char *path, int32_t width, int32_t height, const uint8_t 
  * No counterpart in the reference (it divides directly, include/bvh.hpp:218-229). */
 int rtx_selftest_division(uint64_t n, uint64_t seed, uint64_t *mismatches);
 
+/* Device self-test of the one libm call on the path whose bits are not pinned: pow(x, e) of
+ * the specular term (include/scene.hpp:176) for n seeded cosines in (0, 1] and exponents
+ * 2..1000, against the host's libm.  *differing: results that are not bit-equal; *max_ulps:
+ * the largest distance in units of the last place.  (Exponent 1, the only one the shipped
+ * scenes use, does not go through pow here.)  No counterpart in the reference. */
+int rtx_selftest_pow(uint64_t n, uint64_t seed, uint64_t *differing, uint64_t *max_ulps);
+
 const char *rtx_last_error(void);
 const char *rtx_version(void);
 

@@ -104,7 +104,7 @@ EXPORTS = (
     "rtx_scene_create", "rtx_scene_create_from_host", "rtx_scene_destroy", "rtx_scene_device_bytes",
     "rtx_render_params_default", "rtx_output_pixels", "rtx_render", "rtx_render_device", "rtx_render_device_timed",
     "rtx_untile",
-    "rtx_save_ppm", "rtx_selftest_division", "rtx_last_error", "rtx_version",
+    "rtx_save_ppm", "rtx_selftest_division", "rtx_selftest_pow", "rtx_last_error", "rtx_version",
     "rtx_host_scene_load_obj_ex", "rtx_host_scene_standin_ex",
     "rtx_bvh_build", "rtx_host_scene_rebuild_bvh", "rtx_scene_create_with_builder", "rtx_scene_build_seconds",
     "rtx_scene_bvh_nodes", "rtx_scene_bvh_depth",
@@ -167,6 +167,7 @@ def lib() -> C.CDLL:
     L.rtx_untile.argtypes = [C.POINTER(RenderParams), C.c_int32, vp, vp, C.c_int32, vp]
     L.rtx_save_ppm.argtypes = [C.c_char_p, C.c_int32, C.c_int32, vp]
     L.rtx_selftest_division.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.rtx_selftest_pow.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.rtx_bvh_build.argtypes = [C.POINTER(C.c_double), C.c_uint64, C.c_int32, C.c_int32, vp, C.POINTER(C.c_uint64),
                                 C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
     L.rtx_host_scene_rebuild_bvh.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
@@ -198,6 +199,13 @@ def build_bvh(vertices, builder: int = BUILDER_DEVICE, device: int = -1) -> dict
     _check(lib().rtx_bvh_build(_dptr(v, C.c_double), n, builder, device, nodes.ctypes.data, _dptr(indices, C.c_uint64),
                                C.byref(used), C.byref(depth), C.byref(seconds)))
     return {"nodes": nodes[: used.value].copy(), "indices": indices, "depth": depth.value, "seconds": seconds.value}
+
+
+def selftest_pow(n: int = 1 << 20, seed: int = 1):
+    """(results differing from the host's pow, largest difference in ulps) of the device's pow on the specular domain."""
+    d, m = C.c_uint64(), C.c_uint64()
+    _check(lib().rtx_selftest_pow(n, seed, C.byref(d), C.byref(m)))
+    return d.value, m.value
 
 
 def make_params(width: int, height: int, *, depth: int = 3, spp: int = 1, seed: int = 0,

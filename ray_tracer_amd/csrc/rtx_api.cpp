@@ -841,6 +841,45 @@ int rtx_untile(const rtx_render_params *p, int32_t n_ranks, const void *d_gather
     return RTX_OK;
 }
 
+int rtx_selftest_pow(uint64_t n, uint64_t seed, uint64_t *differing, uint64_t *max_ulps) {
+    if (!differing || !max_ulps) return fail(RTX_ERR_INVALID, "NULL argument");
+    *differing = 0;
+    *max_ulps = 0;
+    if (n == 0) return RTX_OK;
+    // cosines in (0, 1] and the exponents a material can carry (computeLighting, scene.hpp:172-180)
+    std::vector<double> x(n), got(n);
+    std::vector<int32_t> e(n);
+    uint64_t z = seed * 0x9E3779B97F4A7C15ull + 1;
+    auto next = [&]() { z ^= z << 13; z ^= z >> 7; z ^= z << 17; return z; };
+    for (uint64_t i = 0; i < n; i++) {
+        x[i] = (double)((next() >> 11) + 1) * 0x1p-53;                 // (0, 1]
+        if (i % 16 == 0) x[i] = 1.0 - (double)(next() >> 40) * 0x1p-53; // close to 1, where pow loses most
+        static const int32_t menu[] = {2, 3, 5, 8, 10, 16, 32, 50, 64, 100, 250, 1000};
+        e[i] = menu[next() % (sizeof menu / sizeof menu[0])];
+    }
+    double *d_x = nullptr, *d_out = nullptr;
+    int32_t *d_e = nullptr;
+    hipError_t err = hipMalloc((void **)&d_x, n * sizeof(double));
+    if (err == hipSuccess) err = hipMalloc((void **)&d_out, n * sizeof(double));
+    if (err == hipSuccess) err = hipMalloc((void **)&d_e, n * sizeof(int32_t));
+    if (err == hipSuccess) err = hipMemcpy(d_x, x.data(), n * sizeof(double), hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(d_e, e.data(), n * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = rtx::launch_powtest(d_x, d_e, d_out, n, nullptr);
+    if (err == hipSuccess) err = hipMemcpy(got.data(), d_out, n * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(d_x); (void)hipFree(d_out); (void)hipFree(d_e);
+    if (err != hipSuccess) return fail(RTX_ERR_DEVICE, std::string("pow self-test: ") + hipGetErrorString(err));
+    for (uint64_t i = 0; i < n; i++) {
+        const double want = std::pow(x[i], (double)e[i]);
+        int64_t a, b;
+        memcpy(&a, &want, 8);
+        memcpy(&b, &got[i], 8);
+        const uint64_t ulps = (uint64_t)(a > b ? a - b : b - a);      // same sign, finite: ordered like integers
+        if (ulps) (*differing)++;
+        if (ulps > *max_ulps) *max_ulps = ulps;
+    }
+    return RTX_OK;
+}
+
 int rtx_selftest_division(uint64_t n, uint64_t seed, uint64_t *mismatches) {
     if (!mismatches) return fail(RTX_ERR_INVALID, "NULL argument");
     unsigned long long *d = nullptr, h = 0;

@@ -809,6 +809,18 @@ hipError_t launch_render(const DevScene &sc, const DevRender &rp, bool prune, bo
     return hipGetLastError();
 }
 
+// Self-test input/output for the specular term: out[i] = general_pow(x[i], e[i]).
+__global__ void __launch_bounds__(256) powtest_kernel(const double *x, const int32_t *e, double *out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = general_pow(x[i], (double)e[i]);
+}
+
+hipError_t launch_powtest(const double *d_x, const int32_t *d_e, double *d_out, uint64_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(powtest_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, d_x, d_e, d_out, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_divtest(uint64_t seed, uint64_t n, unsigned long long *d_mismatches, hipStream_t st) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(divtest_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, seed, n, d_mismatches);

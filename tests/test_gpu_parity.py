@@ -182,6 +182,15 @@ def test_errors_do_not_cross_as_exceptions_from_c(teapot):
         rt.HostScene.load_obj("/nonexistent/file.obj", "teapot")
 
 
+def test_device_pow_stays_within_two_ulps_of_the_hosts():
+    """The specular term's pow (scene.hpp:176) is the one libm call whose bits are not pinned; this bounds it.
+    A difference of a few ulps in the term moves a colour channel by at most one level, and only when
+    the product lands within 1e-13 of an integer."""
+    differing, max_ulps = rt.selftest_pow(1 << 22, seed=3)
+    print(f"device pow: {differing} of {1 << 22} results differ from glibc, at most {max_ulps} ulp")
+    assert max_ulps <= 2
+
+
 def test_fast_division_is_bit_exact():
     # 2^28 operand pairs per seed, compared bitwise with the compiler's IEEE division on the device
     for seed in (1, 2):
