@@ -151,6 +151,21 @@ __device__ __forceinline__ bool slab_fast(const double *lo, const double *hi, V3
     return tmin < RTX_INF && tmax > 0 && tmax >= tmin;
 }
 
+// v_min_f64 / v_max_f64 as single instructions.  Through __builtin_fmin / __builtin_fmax hipcc
+// first re-quiets every operand it cannot prove canonical (v_max_f64 x, x, x), eight extra
+// instructions per node pair; the operands here are never NaN-signalling (sums, products, fmas
+// or other min/max results).
+__device__ __forceinline__ double vmin(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double vmax(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // The pair test for the common ray: exponents tame (RD_OK) and r.y, r.z non-zero.
 // Every y/z quotient is then finite and not NaN, so std::min/std::max and v_min_f64 /
 // v_max_f64 agree in value and the compare-select chains of slab_fast collapse.
@@ -172,17 +187,17 @@ __device__ __forceinline__ void slab_one_nz(const double *lo, const double *hi, 
     const double az1 = lo[2] - o.z, az2 = hi[2] - o.z;
     const double qz1 = __builtin_fma(__builtin_fma(-r.z, az1 * d.yz, az1), d.yz, az1 * d.yz);
     const double qz2 = __builtin_fma(__builtin_fma(-r.z, az2 * d.yz, az2), d.yz, az2 * d.yz);
-    double nx = __builtin_fmin(qx1, qx2), fx = __builtin_fmax(qx1, qx2);
+    double nx = vmin(qx1, qx2), fx = vmax(qx1, qx2);
     bool x_ok = true;
     if (zx) {
         nx = -RTX_INF;
         fx = RTX_INF;
         x_ok = ax1 < 0.0 && ax2 > 0.0;
     }
-    const double ny = __builtin_fmin(qy1, qy2), fy = __builtin_fmax(qy1, qy2);
-    const double nz = __builtin_fmin(qz1, qz2), fz = __builtin_fmax(qz1, qz2);
-    const double tmin = __builtin_fmax(__builtin_fmax(nx, ny), nz);
-    const double tmax = __builtin_fmin(__builtin_fmin(fx, fy), fz);
+    const double ny = vmin(qy1, qy2), fy = vmax(qy1, qy2);
+    const double nz = vmin(qz1, qz2), fz = vmax(qz1, qz2);
+    const double tmin = vmax(vmax(nx, ny), nz);
+    const double tmax = vmin(vmin(fx, fy), fz);
     *tnear = tmin;
     *beyond = nx > lim.x || ny > lim.y || nz > lim.z;
     *hit = x_ok && tmax > 0 && tmax >= tmin;
