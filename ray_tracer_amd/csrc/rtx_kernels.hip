@@ -326,6 +326,15 @@ struct Scratch {
     __device__ __forceinline__ int32_t &i(uint32_t field) const { return i32[(uint64_t)field * n + id]; }
 };
 
+// What the traversal steps and the scheduler read in every round, fetched from the argument
+// blocks once per wave.
+struct Hot {
+    const DevNode *nodes;
+    const DevTri *tris;
+    uint32_t n_point;
+    int32_t w_inner, w_leaf, w_shade, tail_lanes, also_lanes;
+};
+
 __device__ __forceinline__ void start_query(Lane &L, const DevScene &sc, bool prune) {
     L.rd = make_raydiv(L.o, L.r, sc.fast_div_ok != 0);
     L.slack = prune ? slack_point(L.o, sc.scene_scale) : 0.0;
@@ -377,8 +386,8 @@ __device__ __forceinline__ void pop_node(Lane &L, const DevNode *nodes, const ui
 }
 
 template <bool PRUNE, bool STATS>
-__device__ __forceinline__ void inner_step(Lane &L, const DevScene &sc, uint32_t *stack, uint32_t stride, Counters &c) {
-    const DevNode *nodes = sc.nodes;
+__device__ __forceinline__ void inner_step(Lane &L, const Hot &hot, uint32_t *stack, uint32_t stride, Counters &c) {
+    const DevNode *nodes = hot.nodes;
     // the sibling pair is one 128-byte line: eight 16-byte loads, one round trip
     const d2 *line = reinterpret_cast<const d2 *>(nodes + L.first);
     d2 q0 = line[0], q1 = line[1], q2 = line[2], q3 = line[3], q4 = line[4], q5 = line[5], q6 = line[6], q7 = line[7];
@@ -429,9 +438,9 @@ __device__ __forceinline__ void inner_step(Lane &L, const DevScene &sc, uint32_t
 }
 
 template <bool PRUNE, bool STATS>
-__device__ __forceinline__ void leaf_step(Lane &L, const DevScene &sc, const uint32_t *stack, uint32_t stride, Counters &c) {
+__device__ __forceinline__ void leaf_step(Lane &L, const Hot &hot, const uint32_t *stack, uint32_t stride, Counters &c) {
     // 112 of the record's 128 bytes: seven 16-byte loads, one round trip
-    const d2 *rec = reinterpret_cast<const d2 *>(sc.tris + L.first);
+    const d2 *rec = reinterpret_cast<const d2 *>(hot.tris + L.first);
     d2 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6];
     pin(q0); pin(q1); pin(q2); pin(q3); pin(q4); pin(q5); pin(q6);
     const V3 v0 = {q0.x, q0.y, q1.x}, v1 = {q1.y, q2.x, q2.y}, v2 = {q3.x, q3.y, q4.x}, n = {q4.y, q5.x, q5.y};
@@ -442,11 +451,11 @@ __device__ __forceinline__ void leaf_step(Lane &L, const DevScene &sc, const uin
         if (L.first == leaf_first) c.v[C_LEAVES]++;
     }
     double t;
-    if (tri_hit(v0, v1, v2, n, plane_d, L.o, L.r, &t) && t > query_tmin(L.path) && t < query_tmax(L.path, sc.n_point)) {
+    if (tri_hit(v0, v1, v2, n, plane_d, L.o, L.r, &t) && t > query_tmin(L.path) && t < query_tmax(L.path, hot.n_point)) {
         // equal t: the later leaf wins; inside one leaf the earlier triangle stays (strict <,
         // bvh.hpp:186).  The best hit's leaf is read back only on an exact tie.
         bool better = t < L.best_t;
-        if (t == L.best_t) better = leaf_first > sc.tris[L.best_pos].leaf_first;
+        if (t == L.best_t) better = leaf_first > hot.tris[L.best_pos].leaf_first;
         if (better) {
             L.best_t = t;
             L.best_pos = (int32_t)L.first;
@@ -461,7 +470,7 @@ __device__ __forceinline__ void leaf_step(Lane &L, const DevScene &sc, const uin
     }
     L.first++;
     L.count--;
-    if (L.count == 0) pop_node(L, sc.nodes, stack, stride);
+    if (L.count == 0) pop_node(L, hot.nodes, stack, stride);
 }
 
 // src/main.cpp:78-83: camera ray of pixel (col,row), sample s
@@ -640,6 +649,7 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
     const unsigned long long wave_t0 = (rp.wave_log || rp.ticks) ? wall_clock64() : 0;
 
     const uint32_t stride = rp.stack_stride;
+    const Hot hot = {sc.nodes, sc.tris, sc.n_point, rp.w_inner, rp.w_leaf, rp.w_shade, rp.tail_lanes, rp.also_lanes};
     uint32_t *stack = lds + threadIdx.x;
     const Scratch scr = {rp.scratch_f64, rp.scratch_i32, rp.scratch_lanes, gw * 64u + lane};
     Counters c;
@@ -680,19 +690,19 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
         // few live lanes left (the end of the frame) every kind that has a lane waiting runs, so
         // that no lane sits out a round.
         const int n_inner = __popcll(m_inner), n_leaf = __popcll(m_leaf), n_shade = __popcll(m_shade | m_fetch);
-        const int w_inner = n_inner * rp.w_inner, w_leaf = n_leaf * rp.w_leaf, w_shade = n_shade * rp.w_shade;
-        const bool all_kinds = n_inner + n_leaf + n_shade <= rp.tail_lanes;
+        const int w_inner = n_inner * hot.w_inner, w_leaf = n_leaf * hot.w_leaf, w_shade = n_shade * hot.w_shade;
+        const bool all_kinds = n_inner + n_leaf + n_shade <= hot.tail_lanes;
         const bool pick_inner = w_inner >= w_leaf && w_inner >= w_shade;
         const bool pick_leaf = !pick_inner && w_leaf >= w_shade;
-        if (pick_inner || (all_kinds && n_inner) || n_inner >= rp.also_lanes) {
+        if (pick_inner || (all_kinds && n_inner) || n_inner >= hot.also_lanes) {
             if (STATS && lane == 0) { rounds[0]++; lane_steps[0] += n_inner; }
-            if (L.state == ST_INNER) inner_step<PRUNE, STATS>(L, sc, stack, stride, c);
+            if (L.state == ST_INNER) inner_step<PRUNE, STATS>(L, hot, stack, stride, c);
         }
-        if (pick_leaf || (all_kinds && n_leaf) || n_leaf >= rp.also_lanes) {
+        if (pick_leaf || (all_kinds && n_leaf) || n_leaf >= hot.also_lanes) {
             if (STATS) { const int k = __popcll(__ballot(L.state == ST_LEAF)); if (lane == 0) { rounds[1]++; lane_steps[1] += k; } }
-            if (L.state == ST_LEAF) leaf_step<PRUNE, STATS>(L, sc, stack, stride, c);
+            if (L.state == ST_LEAF) leaf_step<PRUNE, STATS>(L, hot, stack, stride, c);
         }
-        if ((!pick_inner && !pick_leaf) || (all_kinds && n_shade) || n_shade >= rp.also_lanes) {
+        if ((!pick_inner && !pick_leaf) || (all_kinds && n_shade) || n_shade >= hot.also_lanes) {
             if (STATS) { const int k = __popcll(__ballot(L.state == ST_SHADE)); if (lane == 0) { rounds[2]++; lane_steps[2] += k; } }
             if (L.state == ST_SHADE) shade_step<PRUNE, STATS>(L, acc, sc, rp, scr, c);
             // hand pixels to the lanes without one, in lane order
