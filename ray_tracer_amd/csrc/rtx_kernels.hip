@@ -419,18 +419,16 @@ __device__ __forceinline__ void inner_step(Lane &L, const Hot &hot, uint32_t *st
     // {first, count} of each child sit in the fourth 16-byte piece of its record
     const uint32_t af = (uint32_t)__double2loint(q3.x), ac = (uint32_t)__double2hiint(q3.x);
     const uint32_t bf = (uint32_t)__double2loint(q7.x), bc = (uint32_t)__double2hiint(q7.x);
+    // next node: the only child hit, or of two the nearer one (PRUNE) / the left one; the other
+    // one of two goes on the stack
+    const bool take_b = hb && (!ha || (PRUNE && tb < ta));
     if (ha && hb) {
-        const bool b_first = PRUNE && (tb < ta);
-        stack[L.sp * stride] = b_first ? stack_entry(L.first, af, ac) : stack_entry(L.first + 1, bf, bc);
+        stack[L.sp * stride] = take_b ? stack_entry(L.first, af, ac) : stack_entry(L.first + 1, bf, bc);
         L.sp++;
-        L.first = b_first ? bf : af;
-        L.count = b_first ? bc : ac;
-        L.state = L.count ? ST_LEAF : ST_INNER;
-    } else if (ha) {
-        L.first = af; L.count = ac;
-        L.state = L.count ? ST_LEAF : ST_INNER;
-    } else if (hb) {
-        L.first = bf; L.count = bc;
+    }
+    if (ha || hb) {
+        L.first = take_b ? bf : af;
+        L.count = take_b ? bc : ac;
         L.state = L.count ? ST_LEAF : ST_INNER;
     } else {
         pop_node(L, nodes, stack, stride);
