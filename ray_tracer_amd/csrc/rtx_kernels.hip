@@ -357,18 +357,18 @@ __device__ __forceinline__ void start_query(Lane &L, const DevScene &sc, bool pr
 //               hold the node's slot and its header is read.
 // (Triangle positions and node slots stay below 2^28; checked when the scene is created.)
 __device__ __forceinline__ uint32_t stack_entry(uint32_t slot, uint32_t first, uint32_t count) {
-    if (count == 0) return first;
-    if (count <= 7) return 0x80000000u | ((count - 1u) << 28) | first;
-    return 0xF0000000u | slot;
+    const uint32_t small_leaf = 0x80000000u | ((count - 1u) << 28) | first;
+    const uint32_t leaf = count <= 7u ? small_leaf : (0xF0000000u | slot);
+    return count == 0u ? first : leaf;
 }
 
-__device__ __forceinline__ void pop_node(Lane &L, const DevNode *nodes, const uint32_t *stack, uint32_t stride) {
+__device__ __forceinline__ void pop_node(Lane &L, const DevNode *nodes, const uint32_t *stack, uint32_t stride) {   // stride: log2 of the lanes per stack level
     if (L.sp == 0) {
         L.state = ST_SHADE;
         return;
     }
     L.sp--;
-    const uint32_t e = stack[L.sp * stride];
+    const uint32_t e = stack[L.sp << stride];
     if ((e & 0x80000000u) == 0) {
         L.first = e;
         L.count = 0;
@@ -423,7 +423,8 @@ __device__ __forceinline__ void inner_step(Lane &L, const Hot &hot, uint32_t *st
     // one of two goes on the stack
     const bool take_b = hb && (!ha || (PRUNE && tb < ta));
     if (ha && hb) {
-        stack[L.sp * stride] = take_b ? stack_entry(L.first, af, ac) : stack_entry(L.first + 1, bf, bc);
+        // the child that is not taken
+        stack[L.sp << stride] = stack_entry(take_b ? L.first : L.first + 1u, take_b ? af : bf, take_b ? ac : bc);
         L.sp++;
     }
     if (ha || hb) {
@@ -646,7 +647,8 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
     const uint64_t gw = (uint64_t)blockIdx.x * waves_per_block + wave;   // resident wave slot
     const unsigned long long wave_t0 = (rp.wave_log || rp.ticks) ? wall_clock64() : 0;
 
-    const uint32_t stride = rp.stack_stride;
+    // the stack of a lane is strided by the block size, a power of two: levels are shifted, not multiplied
+    const uint32_t stride = 31u - (uint32_t)__builtin_clz(rp.stack_stride);
     const Hot hot = {sc.nodes, sc.tris, sc.n_point, rp.w_inner, rp.w_leaf, rp.w_shade, rp.tail_lanes, rp.also_lanes};
     uint32_t *stack = lds + threadIdx.x;
     const Scratch scr = {rp.scratch_f64, rp.scratch_i32, rp.scratch_lanes, gw * 64u + lane};
