@@ -369,19 +369,14 @@ __device__ __forceinline__ void pop_node(Lane &L, const DevNode *nodes, const ui
     }
     L.sp--;
     const uint32_t e = stack[L.sp << stride];
-    if ((e & 0x80000000u) == 0) {
-        L.first = e;
-        L.count = 0;
-        L.state = ST_INNER;
-    } else if ((e >> 28) != 0xFu) {
-        L.first = e & 0x0FFFFFFFu;
-        L.count = ((e >> 28) & 7u) + 1u;
-        L.state = ST_LEAF;
-    } else {
+    const bool leaf = (e & 0x80000000u) != 0;
+    L.first = leaf ? (e & 0x0FFFFFFFu) : e;
+    L.count = leaf ? ((e >> 28) & 7u) + 1u : 0u;
+    L.state = leaf ? ST_LEAF : ST_INNER;
+    if ((e >> 28) == 0xFu) {               // a leaf of more than 7 triangles: its header says where
         const uint32_t slot = e & 0x0FFFFFFFu;
         L.first = nodes[slot].first;
         L.count = nodes[slot].count;
-        L.state = ST_LEAF;
     }
 }
 
