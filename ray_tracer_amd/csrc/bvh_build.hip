@@ -23,8 +23,11 @@
 //    pair index follows from the number of inner nodes before it in pre-order, which is
 //    (inner nodes with a smaller `first`) + (ancestors with the same `first`).
 //
-// The tree is built breadth-first, one level per iteration, in temporary node records,
-// and renumbered at the end.
+// Nodes with more than kSmall triangles are built breadth-first, one level per iteration
+// (bounds, bins, plane choice, flags + prefix counts, children, two scatter passes), in
+// temporary node records; every node with at most kSmall triangles is handed to one wave
+// that builds its whole subtree in registers (subtree_kernel).  The records are renumbered
+// into the reference's order at the end.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
