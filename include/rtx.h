@@ -257,6 +257,9 @@ int rtx_untile(const rtx_render_params *p, int32_t n_ranks, const void *d_gather
 
 /* saveCanvas (src/main.cpp:96-116): binary P6, "P6\n<W> <H> 255\n" + rows. */
 int rtx_save_ppm(const char *path, int32_t width, int32_t height, const uint8_t *rgb);
+/* The same canvas as an 8-bit RGB PNG (uncompressed deflate blocks).  No counterpart in the
+ * reference, whose PNGs under images/ were converted by hand. */
+int rtx_save_png(const char *path, int32_t width, int32_t height, const uint8_t *rgb);
 
 /* Device self-test of the slab test's division-by-ray-constant: n seeded operand pairs
  * (zeros, powers of two, all-ones significands, exponents over the admitted range) are

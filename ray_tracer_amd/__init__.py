@@ -104,7 +104,7 @@ EXPORTS = (
     "rtx_scene_create", "rtx_scene_create_from_host", "rtx_scene_destroy", "rtx_scene_device_bytes",
     "rtx_render_params_default", "rtx_output_pixels", "rtx_render", "rtx_render_device", "rtx_render_device_timed",
     "rtx_untile",
-    "rtx_save_ppm", "rtx_selftest_division", "rtx_selftest_pow", "rtx_last_error", "rtx_version",
+    "rtx_save_ppm", "rtx_save_png", "rtx_selftest_division", "rtx_selftest_pow", "rtx_last_error", "rtx_version",
     "rtx_host_scene_load_obj_ex", "rtx_host_scene_standin_ex",
     "rtx_bvh_build", "rtx_host_scene_rebuild_bvh", "rtx_scene_create_with_builder", "rtx_scene_build_seconds",
     "rtx_scene_bvh_nodes", "rtx_scene_bvh_depth",
@@ -166,6 +166,7 @@ def lib() -> C.CDLL:
     L.rtx_render_device_timed.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, vp, vp, vp, vp]
     L.rtx_untile.argtypes = [C.POINTER(RenderParams), C.c_int32, vp, vp, C.c_int32, vp]
     L.rtx_save_ppm.argtypes = [C.c_char_p, C.c_int32, C.c_int32, vp]
+    L.rtx_save_png.argtypes = [C.c_char_p, C.c_int32, C.c_int32, vp]
     L.rtx_selftest_division.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
     L.rtx_selftest_pow.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.rtx_bvh_build.argtypes = [C.POINTER(C.c_double), C.c_uint64, C.c_int32, C.c_int32, vp, C.POINTER(C.c_uint64),
@@ -451,3 +452,10 @@ def save_ppm(path: str, rgb: np.ndarray) -> None:
     a = np.ascontiguousarray(rgb, dtype=np.uint8)
     h, w = a.shape[:2]
     _check(lib().rtx_save_ppm(os.fsencode(path), w, h, a.ctypes.data))
+
+
+def save_png(path: str, rgb: np.ndarray) -> None:
+    """The canvas as an 8-bit RGB PNG."""
+    a = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w = a.shape[:2]
+    _check(lib().rtx_save_png(os.fsencode(path), w, h, a.ctypes.data))

@@ -905,4 +905,77 @@ int rtx_save_ppm(const char *path, int32_t width, int32_t height, const uint8_t 
     return RTX_OK;
 }
 
+// The same canvas as a PNG (8-bit RGB, rows unfiltered, deflate "stored" blocks: no compression
+// library needed and nothing to get wrong; a 4K frame is 24.9 MB either way).
+int rtx_save_png(const char *path, int32_t width, int32_t height, const uint8_t *rgb) {
+    if (!path || !rgb || width <= 0 || height <= 0) return fail(RTX_ERR_INVALID, "bad argument");
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(RTX_ERR_IO, "Failed to open file.\n");
+    static uint32_t table[256];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (uint32_t n = 0; n < 256; n++) {
+            uint32_t c = n;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[n] = c;
+        }
+    });
+    auto crc = [&](uint32_t c, const uint8_t *p, size_t n) { while (n--) c = table[(c ^ *p++) & 0xff] ^ (c >> 8); return c; };
+    auto be32 = [](uint8_t *p, uint32_t v) { p[0] = v >> 24; p[1] = v >> 16; p[2] = v >> 8; p[3] = v; };
+    bool ok = true;
+    auto chunk = [&](const char type[4], const std::vector<uint8_t> &data) {
+        uint8_t head[8], tail[4];
+        be32(head, (uint32_t)data.size());
+        memcpy(head + 4, type, 4);
+        uint32_t c = crc(0xffffffffu, head + 4, 4);
+        c = crc(c, data.data(), data.size()) ^ 0xffffffffu;
+        be32(tail, c);
+        ok = ok && fwrite(head, 1, 8, f) == 8 && (data.empty() || fwrite(data.data(), 1, data.size(), f) == data.size()) &&
+             fwrite(tail, 1, 4, f) == 4;
+    };
+    static const uint8_t magic[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    ok = fwrite(magic, 1, 8, f) == 8;
+    std::vector<uint8_t> ihdr(13, 0);
+    be32(&ihdr[0], (uint32_t)width);
+    be32(&ihdr[4], (uint32_t)height);
+    ihdr[8] = 8;    // bit depth
+    ihdr[9] = 2;    // colour type: RGB
+    chunk("IHDR", ihdr);
+    // scanlines: filter byte 0 + row
+    const size_t row = (size_t)width * 3, raw = (row + 1) * (size_t)height;
+    std::vector<uint8_t> z;
+    z.reserve(raw + raw / 65535 * 5 + 16);
+    z.push_back(0x78);
+    z.push_back(0x01);
+    uint32_t a = 1, b = 0;                       // Adler-32 of the raw stream
+    std::vector<uint8_t> line(row + 1, 0);
+    size_t in_block = 0;
+    auto open_block = [&](size_t remaining) {
+        const size_t n = remaining < 65535 ? remaining : 65535;
+        z.push_back(remaining <= 65535 ? 1 : 0);  // BFINAL, BTYPE = 00
+        z.push_back(n & 0xff); z.push_back(n >> 8);
+        z.push_back(~n & 0xff); z.push_back((~n >> 8) & 0xff);
+        in_block = n;
+    };
+    size_t remaining = raw;
+    open_block(remaining);
+    for (int32_t y = 0; y < height; y++) {
+        memcpy(&line[1], rgb + (size_t)y * row, row);
+        for (size_t i = 0; i < line.size();) {
+            if (in_block == 0) open_block(remaining);
+            const size_t n = std::min(in_block, line.size() - i);
+            z.insert(z.end(), line.begin() + i, line.begin() + i + n);
+            for (size_t k = 0; k < n; k++) { a += line[i + k]; if (a >= 65521) a -= 65521; b += a; if (b >= 65521) b -= 65521; }
+            i += n; in_block -= n; remaining -= n;
+        }
+    }
+    uint8_t ad[4];
+    be32(ad, (b << 16) | a);
+    z.insert(z.end(), ad, ad + 4);
+    chunk("IDAT", z);
+    chunk("IEND", {});
+    if (fclose(f) != 0 || !ok) return fail(RTX_ERR_IO, "short write");
+    return RTX_OK;
+}
+
 }  // extern "C"

@@ -189,3 +189,28 @@ def test_tolerant_loader_errors(tmp_path):
         rt.HostScene.load_obj(str(bad), "teapot", tolerant=True)
     with pytest.raises(rt.RtxError, match="Failed to open file"):
         rt.HostScene.load_obj(str(tmp_path / "missing.obj"), "teapot", tolerant=True)
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (7, 5), (300, 217), (1920, 37)])
+def test_png_writer_round_trips(tmp_path, w, h):
+    """Decoded with zlib and struct only: signature, IHDR, one IDAT of stored blocks, IEND, every CRC."""
+    import struct, zlib
+    rng = np.random.default_rng(w * 1000 + h)
+    img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    path = tmp_path / "x.png"
+    rt.save_png(str(path), img)
+    data = path.read_bytes()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(data):
+        n, kind = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        (crc,) = struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])
+        assert crc == zlib.crc32(kind + body)
+        chunks.append((kind, body))
+        pos += 12 + n
+    assert [k for k, _ in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    assert struct.unpack(">IIBBBBB", chunks[0][1]) == (w, h, 8, 2, 0, 0, 0)
+    raw = np.frombuffer(zlib.decompress(chunks[1][1]), dtype=np.uint8).reshape(h, 1 + 3 * w)
+    assert (raw[:, 0] == 0).all()
+    assert np.array_equal(raw[:, 1:].reshape(h, w, 3), img)
