@@ -257,3 +257,56 @@ def test_extreme_ray_components_take_the_plain_division_path(mode):
         st.pop("kernel_ms")
         assert st == want["census"].as_dict()
     dev.close()
+
+
+def _scene_from(v, seed, camera_position=(0.3, 0.2, -6.0)):
+    rng = np.random.default_rng(seed)
+    n = v.shape[0]
+    col = rng.integers(0, 256, size=(n, 3)).astype(np.int32)
+    spec = rng.choice(np.array([-1, 1], dtype=np.int32), size=n)
+    refl = rng.choice(np.array([-1.0, 0.3, 0.8]), size=n)
+    cam = dict(camera_position=camera_position, camera_rotation_deg=(2.0, -3.0, 1.0), ambient=0.2,
+               point_lights=[(0.5, (1.0, 4.0, -2.0))], directional_lights=[(0.4, (0.0, 1.0, -1.0))])
+    host = rt.HostScene.from_arrays(v, col, spec, refl, **cam)
+    return host, rt.Scene(host), OracleScene.from_arrays(v, col, spec, refl, **cam)
+
+
+@pytest.mark.parametrize("mode", [rt.TRAVERSAL_REFERENCE, rt.TRAVERSAL_PRUNED])
+def test_deep_tree_runs_with_smaller_blocks(mode):
+    """Triangles at geometrically growing distances: every split peels one off, the tree is a chain more than
+    64 levels deep, and the per-lane traversal stack only fits LDS with fewer than 256 lanes per block."""
+    n = 80
+    rng = np.random.default_rng(1)
+    z = 4 + 1e-3 * 8.0 ** np.arange(n)               # every triangle 8x farther than the previous one
+    size = z * 0.15
+    c = np.stack([rng.uniform(-0.3, 0.3, n) * z, rng.uniform(-0.3, 0.3, n) * z, z], 1)
+    corners = np.stack([np.stack([-size, -size, 0 * size], 1), np.stack([size, -size, 0 * size], 1),
+                        np.stack([0 * size, size, 0 * size], 1)], 1)
+    v = (c[:, None, :] + corners).reshape(n, 9)
+    host, dev, ora = _scene_from(v, 5)
+    assert host.bvh_depth > 64
+    want = ora.render(128, 96, depth=3)
+    got = dev.render(128, 96, depth=3, traversal=mode, want_stats=True)
+    assert np.array_equal(got.hit, want["hit"]) and np.array_equal(got.rgb, want["rgb_u8"])
+    if mode == rt.TRAVERSAL_REFERENCE:
+        st = got.stats.as_dict()
+        st.pop("kernel_ms")
+        assert st == want["census"].as_dict()
+    dev.close()
+
+
+@pytest.mark.parametrize("mode", [rt.TRAVERSAL_REFERENCE, rt.TRAVERSAL_PRUNED])
+def test_leaf_with_many_identical_triangles(mode):
+    """40 copies of one triangle cannot be separated: one leaf of 40 (more than a stack entry can describe inline);
+    all of them tie in t and the first in the leaf's index order must win."""
+    rng = np.random.default_rng(9)
+    v = rng.uniform(-3, 3, size=(200, 1, 3)) + np.array([0, 0, 9.0]) + rng.uniform(-0.8, 0.8, size=(200, 3, 3))
+    v[50:90] = np.array([[-2.5, -2.0, 6.0], [2.5, -2.0, 6.0], [0.0, 2.5, 6.5]])
+    host, dev, ora = _scene_from(v.reshape(-1, 9), 6)
+    assert host.arrays()["nodes"]["count"].max() >= 40
+    want = ora.render(160, 120, depth=3)
+    got = dev.render(160, 120, depth=3, traversal=mode)
+    assert np.array_equal(got.hit, want["hit"]) and np.array_equal(got.rgb, want["rgb_u8"])
+    copies = np.unique(got.hit[(got.hit >= 50) & (got.hit < 90)])
+    assert copies.size == 1                     # one of the 40 wins everywhere: the first in the leaf's index order
+    dev.close()
