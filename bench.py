@@ -109,14 +109,6 @@ def main():
             dist.all_reduce(h)
             t.copy_(h)
 
-    def all_gather(out, local):
-        if args.backend == "nccl":
-            dist.all_gather_into_tensor(out, local)
-        else:
-            parts = [torch.empty(local.numel(), dtype=local.dtype) for _ in range(world)]
-            dist.all_gather(parts, local.cpu())
-            out.copy_(torch.cat(parts))
-
     W, H = args.width, args.height
     mode = rt.TRAVERSAL_PRUNED if args.mode == "pruned" else rt.TRAVERSAL_REFERENCE
     tmp = os.environ.get("TMPDIR", "/tmp")
@@ -139,19 +131,14 @@ def main():
     create_s = time.time() - t0
 
     packed = world > 1
-    params = rt.make_params(W, H, depth=args.depth, spp=args.spp, traversal=mode, tile=(args.tile, args.tile),
-                            tile_rank=rank, tile_count=world,
-                            layout=rt.LAYOUT_PACKED_TILES if packed else rt.LAYOUT_ROW_MAJOR)
-    import ctypes as C
-    px = int(rt.lib().rtx_output_pixels(C.byref(params)))
     F = max(1, min(8, args.inflight))
-    # one set of buffers and one stream per frame in flight
-    bufs = [torch.zeros(px * 3, dtype=torch.uint8, device=dev) for _ in range(F)]
-    frames = [torch.zeros(H * W * 3, dtype=torch.uint8, device=dev) for _ in range(F)]
-    gathers = [torch.zeros(world * px * 3, dtype=torch.uint8, device=dev) if packed else None for _ in range(F)]
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(F - 1)]
-    buf, frame = bufs[0], frames[0]
-    stream = streams[0].cuda_stream
+    # the product's multi-GPU frame loop: render own tiles -> all-gather -> re-assembly, F frames in flight
+    from ray_tracer_amd.distributed import ShardedRenderer
+    renderer = ShardedRenderer(scene, W, H, rank, world, dev, tile=args.tile, inflight=F, depth=args.depth, spp=args.spp,
+                               traversal=mode)
+    params = renderer.params
+    frames, buf = renderer.frames, renderer.locals[0]
+    stream = renderer.streams[0].cuda_stream
 
     def census(traversal):
         """Untimed pre-pass with the counting kernel: rays and canonical work of this rank's tiles."""
@@ -173,24 +160,17 @@ def main():
     alg_bytes_frame = cen_ref["node_visits"] * 64 + cen_ref["triangle_tests"] * 96
     bytes_per_ray = alg_bytes_frame / max(1, rays)
 
-    out_ptr = frame.data_ptr() if not packed else buf.data_ptr()
+    out_ptr = buf.data_ptr()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     # device-side start/end of every timed launch (100 MHz ticks), written by the kernel itself
     ticks = torch.zeros(max(1, args.steps) * 2, dtype=torch.int64, device=dev)
 
     def step(k, i=None):
-        """Frame number k: render (+ all-gather and re-assembly) on stream k % F."""
-        slot = k % F
-        with torch.cuda.stream(streams[slot]):
-            if i is not None:
-                ev[i][0].record()
-            scene.render_device(params, rgb_u8=(frames[slot] if not packed else bufs[slot]).data_ptr(),
-                                ticks=ticks[2 * i:].data_ptr() if i is not None else 0, stream=streams[slot].cuda_stream)
-            if i is not None:
-                ev[i][1].record()
-            if packed:
-                all_gather(gathers[slot], bufs[slot])
-                rt.untile(params, world, gathers[slot].data_ptr(), frames[slot].data_ptr(), 3, streams[slot].cuda_stream)
+        """Frame number k on stream k % F; the timed ones leave stream events and device clock values."""
+        if i is None:
+            renderer.submit()
+        else:
+            renderer.submit(events=ev[i], ticks=ticks[2 * i:].data_ptr())
 
     for k in range(args.warmup):
         step(k)

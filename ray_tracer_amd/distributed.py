@@ -42,23 +42,60 @@ def gather_packed(local: torch.Tensor, world: int, group=None) -> torch.Tensor:
 
 
 class ShardedRenderer:
-    """Keeps the device buffers of one rank and renders whole frames cooperatively."""
+    """Keeps the device buffers of one rank and renders whole frames cooperatively.
+
+    `inflight` frames may be in progress at once: frame k is rendered, gathered and re-assembled on
+    stream k % inflight with its own buffers, so the end of a frame (lanes running dry), its
+    all-gather and its re-assembly overlap the next frame's render.  4 = one stream per hardware
+    queue of the process.
+    """
 
     def __init__(self, scene: Scene, width: int, height: int, rank: int, world: int, device: torch.device, *,
-                 tile: int = 32, group=None, **render_kw):
+                 tile: int = 32, group=None, inflight: int = 1, **render_kw):
         self.scene, self.rank, self.world, self.group = scene, rank, world, group
         self.width, self.height = width, height
         self.params = shard_params(width, height, rank, world, tile=tile, **render_kw)
+        self.inflight = max(1, min(8, int(inflight)))
         n = output_pixels(self.params) * 3
-        self.frame = torch.zeros(height * width * 3, dtype=torch.uint8, device=device)
-        self.local = self.frame if world == 1 else torch.zeros(n, dtype=torch.uint8, device=device)
-        self.gathered = None if world == 1 else torch.zeros(world * n, dtype=torch.uint8, device=device)
+        self.frames = [torch.zeros(height * width * 3, dtype=torch.uint8, device=device) for _ in range(self.inflight)]
+        self.locals = self.frames if world == 1 else [torch.zeros(n, dtype=torch.uint8, device=device) for _ in range(self.inflight)]
+        self.gathers = [None if world == 1 else torch.zeros(world * n, dtype=torch.uint8, device=device)
+                        for _ in range(self.inflight)]
+        with torch.cuda.device(device):
+            self.streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=device) for _ in range(self.inflight - 1)]
+        # a process group without device collectives (gloo) gathers through host memory: rehearsals only
+        self._host_gather = world > 1 and dist.get_backend(group) != "nccl"
+        self._next = 0
+
+    def submit(self, *, events=None, ticks: int = 0) -> int:
+        """Queues the next frame and returns its slot; `frames[slot]` is complete once `streams[slot]` has
+        drained.  events: an optional (start, end) pair of torch events recorded around the render kernel;
+        ticks: device pointer for rtx_render_device_timed's two clock values."""
+        slot = self._next % self.inflight
+        self._next += 1
+        stream = self.streams[slot]
+        with torch.cuda.stream(stream):
+            if events is not None:
+                events[0].record()
+            self.scene.render_device(self.params, rgb_u8=self.locals[slot].data_ptr(), ticks=ticks, stream=stream.cuda_stream)
+            if events is not None:
+                events[1].record()
+            if self.world > 1:
+                if self._host_gather:
+                    parts = [torch.empty(self.locals[slot].numel(), dtype=torch.uint8) for _ in range(self.world)]
+                    dist.all_gather(parts, self.locals[slot].cpu(), group=self.group)
+                    self.gathers[slot].copy_(torch.cat(parts))
+                else:
+                    dist.all_gather_into_tensor(self.gathers[slot], self.locals[slot], group=self.group)
+                untile(self.params, self.world, self.gathers[slot].data_ptr(), self.frames[slot].data_ptr(), 3, stream.cuda_stream)
+        return slot
+
+    def synchronize(self) -> None:
+        for s in self.streams:
+            s.synchronize()
 
     def render(self) -> torch.Tensor:
-        """One frame; returns the row-major (H*W*3,) uint8 tensor (valid on every rank)."""
-        stream = torch.cuda.current_stream().cuda_stream
-        self.scene.render_device(self.params, rgb_u8=self.local.data_ptr(), stream=stream)
-        if self.world > 1:
-            dist.all_gather_into_tensor(self.gathered, self.local, group=self.group)
-            untile(self.params, self.world, self.gathered.data_ptr(), self.frame.data_ptr(), 3, stream)
-        return self.frame
+        """One frame, finished; returns the row-major (H*W*3,) uint8 tensor (valid on every rank)."""
+        slot = self.submit()
+        self.streams[slot].synchronize()
+        return self.frames[slot]

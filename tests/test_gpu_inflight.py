@@ -40,3 +40,19 @@ def test_overlapping_frames_equal_frames_rendered_alone():
             assert np.array_equal(bufs[k].cpu().numpy(), alone[k]), (rep, k)
     t = ticks.cpu().numpy().reshape(-1, 2)
     assert (t[:, 1] > t[:, 0]).all()           # every launch left its start and end on the device clock
+
+
+def test_sharded_renderer_single_rank_with_frames_in_flight():
+    import torch
+    from ray_tracer_amd.distributed import ShardedRenderer
+    hs = rt.HostScene.load_obj(os.path.join(HERE, "golden", "teapot.obj"), "teapot", no_bvh=True)
+    scene = rt.Scene(hs)
+    want = scene.render(320, 200, traversal=rt.TRAVERSAL_PRUNED).rgb
+    r = ShardedRenderer(scene, 320, 200, 0, 1, torch.device("cuda", torch.cuda.current_device()), inflight=4,
+                        traversal=rt.TRAVERSAL_PRUNED)
+    slots = [r.submit() for _ in range(9)]
+    r.synchronize()
+    assert slots == [0, 1, 2, 3, 0, 1, 2, 3, 0]
+    for f in r.frames:
+        assert np.array_equal(f.cpu().numpy().reshape(200, 320, 3), want)
+    assert np.array_equal(r.render().cpu().numpy().reshape(200, 320, 3), want)
