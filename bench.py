@@ -28,7 +28,8 @@ def profiled_traffic(workload_key):
     prescribes, WRITE_SIZE taken as is; both are reported in KiB by rocprofv3."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[workload_key]
-        return {"bytes": int((2 * t["FETCH_SIZE_KiB"] + t["WRITE_SIZE_KiB"]) * 1024), "source": t["source"]}
+        return {"bytes": int((2 * t["FETCH_SIZE_KiB"] + t["WRITE_SIZE_KiB"]) * 1024), "source": t["source"],
+                "valu_instructions": t.get("SQ_INSTS_VALU")}
     except Exception:
         return None
 
@@ -276,6 +277,17 @@ def main():
                     "returns the same pixels while visiting fewer nodes, so frac can exceed 1; other_mode "
                     "gives the same arithmetic for the kernel that does exactly the canonical visits. "
                     "Scenes under 256 MiB are served from L2 / Infinity Cache: HBM is not the binding limit",
+        },
+        # second bound, from the same committed counter pass: wave-level VALU instructions of one launch; a
+        # wave64 instruction occupies a 16-lane SIMD for 4 cycles, the chip has 4 SIMDs per CU
+        "valu_issue": None if not (traffic and traffic.get("valu_instructions")) else {
+            "wave_instructions_per_launch": int(traffic["valu_instructions"]),
+            "simds": 4 * int(torch.cuda.get_device_properties(dev).multi_processor_count),
+            "clock_ghz": 2.4,
+            "min_ms_per_launch": round(traffic["valu_instructions"] * 4 /
+                                       (4 * torch.cuda.get_device_properties(dev).multi_processor_count * 2.4e9) * 1e3, 3),
+            "frac_of_ms_per_step": round(traffic["valu_instructions"] * 4 /
+                                         (4 * torch.cuda.get_device_properties(dev).multi_processor_count * 2.4e9) * 1e3 / ms_per_step, 4),
         },
         "other_mode": {
             "traversal": "reference" if other_mode == rt.TRAVERSAL_REFERENCE else "pruned",

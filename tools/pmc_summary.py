@@ -26,4 +26,6 @@ if len(sys.argv) >= 5 and "FETCH_SIZE" in out and "WRITE_SIZE" in out:
     table = json.load(open(path)) if os.path.exists(path) else {}
     table[key] = {"FETCH_SIZE_KiB": out["FETCH_SIZE"]["mean_per_dispatch"], "WRITE_SIZE_KiB": out["WRITE_SIZE"]["mean_per_dispatch"],
                   "source": os.path.basename(sys.argv[2])}
+    if "SQ_INSTS_VALU" in out:
+        table[key]["SQ_INSTS_VALU"] = out["SQ_INSTS_VALU"]["mean_per_dispatch"]
     json.dump(table, open(path, "w"), indent=1, sort_keys=True)
