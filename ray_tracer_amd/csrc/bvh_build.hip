@@ -96,14 +96,60 @@ __device__ __forceinline__ void init_node(const Nodes &nd, uint32_t t, uint32_t 
     }
 }
 
-// Triangle::centroid as the Triangle ctor computes it (include/triangle.hpp:24).
-__global__ void centroid_kernel(const double *__restrict__ V, double *__restrict__ C, uint32_t *__restrict__ idx,
+// What every pass needs of a triangle, computed once: the keys of its box, its centroid and, per
+// axis, which of its vertices is the last one with a zero coordinate (3 bits per axis:
+// (vertex + 1) << 1 | 1 for +0, 0 = no zero) for the sign bookkeeping of the stored bounds.
+struct alignas(16) TriRec {
+    uint64_t lo[3], hi[3];
+    double c[3];
+    uint32_t zeros, pad;
+};
+static_assert(sizeof(TriRec) == 80, "TriRec");
+
+__device__ __forceinline__ TriRec load_tri(const TriRec *__restrict__ T, uint32_t t) {
+    // five 16-byte loads
+    const uint4 *q = reinterpret_cast<const uint4 *>(T + t);
+    const uint4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4];
+    TriRec r;
+    auto u64 = [](uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; };
+    r.lo[0] = u64(a.x, a.y); r.lo[1] = u64(a.z, a.w); r.lo[2] = u64(b.x, b.y);
+    r.hi[0] = u64(b.z, b.w); r.hi[1] = u64(c.x, c.y); r.hi[2] = u64(c.z, c.w);
+    r.c[0] = __longlong_as_double((long long)u64(d.x, d.y)); r.c[1] = __longlong_as_double((long long)u64(d.z, d.w));
+    r.c[2] = __longlong_as_double((long long)u64(e.x, e.y));
+    r.zeros = e.z; r.pad = 0;
+    return r;
+}
+// Tracker value of a triangle at sequence position p for one axis (see Nodes::zero).
+__device__ __forceinline__ uint64_t zero_key(uint32_t zeros, int axis, uint64_t p) {
+    const uint32_t zi = (zeros >> (3 * axis)) & 7u;
+    return zi ? ((p * 3 + (zi >> 1)) << 1) | (zi & 1u) : 0ull;
+}
+
+// Triangle::centroid as the Triangle ctor computes it (include/triangle.hpp:24), and the record above.
+__global__ void centroid_kernel(const double *__restrict__ V, TriRec *__restrict__ T, uint32_t *__restrict__ idx,
                                 uint32_t *__restrict__ node_of, uint32_t n, Nodes nd) {
     const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     if (p == 0) init_node(nd, 0, 0, n, 0, 0);
     if (p >= n) return;
     const double *v = V + 9 * (size_t)p;
-    for (int k = 0; k < 3; k++) C[3 * (size_t)p + k] = ((v[k] + v[3 + k]) + v[6 + k]) / 3;
+    TriRec r;
+    r.zeros = 0; r.pad = 0;
+    for (int k = 0; k < 3; k++) {
+        const double a = v[k], b = v[3 + k], c = v[6 + k];
+        const uint64_t ka = key_of(a), kb = key_of(b), kc = key_of(c);
+        uint64_t m = ka < kb ? ka : kb;
+        r.lo[k] = m < kc ? m : kc;
+        m = ka > kb ? ka : kb;
+        r.hi[k] = m > kc ? m : kc;
+        r.c[k] = ((a + b) + c) / 3;
+        // the last coordinate of this triangle that is a zero, in the order v0, v1, v2
+        uint32_t zi = 0;
+        if (a == 0.0) zi = (1u << 1) | (uint32_t)(ka >> 63);
+        if (b == 0.0) zi = (2u << 1) | (uint32_t)(kb >> 63);
+        if (c == 0.0) zi = (3u << 1) | (uint32_t)(kc >> 63);
+        r.zeros |= zi << (3 * k);
+    }
+    T[p] = r;
     idx[p] = p;
     node_of[p] = 0;
 }
@@ -131,8 +177,7 @@ __device__ __forceinline__ uint64_t run_reduce(uint64_t v, uint32_t node, int la
 // A block walks `tiles_per_block` consecutive tiles of kFat positions.  Tiles that lie
 // inside one node are accumulated in LDS across tiles, so that a large node receives one
 // set of atomics per block; other tiles send one set per run of lanes that share a node.
-__global__ __launch_bounds__(kFat) void bounds_kernel(const double *__restrict__ V, const double *__restrict__ C,
-                                                      const uint32_t *__restrict__ idx, const uint32_t *__restrict__ node_of,
+__global__ __launch_bounds__(kFat) void bounds_kernel(const TriRec *__restrict__ T, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ node_of,
                                                       uint32_t n, Nodes nd, uint32_t tiles_per_block) {
     // 0-2 bmin, 3-5 bmax, 6-8 centroid min, 9-11 centroid max, 12-14 zero trackers
     __shared__ unsigned long long s_acc[15];
@@ -167,25 +212,13 @@ __global__ __launch_bounds__(kFat) void bounds_kernel(const double *__restrict__
         }
         uint64_t lo[3], hi[3], clo[3], chi[3], zs[3];
         if (node != kInactive) {
-            const uint32_t t = idx[p];
-            const double *v = V + 9 * (size_t)t;
+            const TriRec r = load_tri(T, idx[p]);
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                const double a = v[k], b = v[3 + k], c = v[6 + k];
-                const uint64_t ka = key_of(a), kb = key_of(b), kc = key_of(c);
-                uint64_t m = ka < kb ? ka : kb;
-                lo[k] = m < kc ? m : kc;
-                m = ka > kb ? ka : kb;
-                hi[k] = m > kc ? m : kc;
-                // the last coordinate of this triangle that is a zero, in the order v0, v1, v2
-                uint64_t z = 0;
-                if (a == 0.0) z = (((uint64_t)p * 3 + 0 + 1) << 1) | (ka >> 63);
-                if (b == 0.0) z = (((uint64_t)p * 3 + 1 + 1) << 1) | (kb >> 63);
-                if (c == 0.0) z = (((uint64_t)p * 3 + 2 + 1) << 1) | (kc >> 63);
-                zs[k] = z;
-                const uint64_t kcen = key_of(C[3 * (size_t)t + k]);
-                clo[k] = kcen;
-                chi[k] = kcen;
+                lo[k] = r.lo[k];
+                hi[k] = r.hi[k];
+                zs[k] = zero_key(r.zeros, k, p);
+                clo[k] = chi[k] = key_of(r.c[k]);
             }
         } else {
 #pragma unroll
@@ -230,8 +263,7 @@ constexpr int kBinSlots = 3 * kBins;
 // node of the level.  Same tiling as bounds_kernel: tiles inside one node fill one set of
 // bins in LDS per block; in other tiles each wave accumulates every run of lanes that
 // share a node in its own LDS bins and adds the non-empty ones to the node's bins.
-__global__ __launch_bounds__(kFat) void bin_kernel(const double *__restrict__ V, const double *__restrict__ C,
-                                                   const uint32_t *__restrict__ idx, const uint32_t *__restrict__ node_of,
+__global__ __launch_bounds__(kFat) void bin_kernel(const TriRec *__restrict__ T, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ node_of,
                                                    uint32_t n, Nodes nd, Bins bins, uint32_t level_begin,
                                                    uint32_t tiles_per_block) {
     constexpr int kWaves = kFat / 64;
@@ -277,22 +309,15 @@ __global__ __launch_bounds__(kFat) void bin_kernel(const double *__restrict__ V,
         int bin[3] = {-1, -1, -1};
         uint64_t lo[3], hi[3];
         if (node != kInactive) {
-            const uint32_t t = idx[p];
-            const double *v = V + 9 * (size_t)t;
+            const TriRec r = load_tri(T, idx[p]);
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const uint64_t ka = key_of(v[k]), kb = key_of(v[3 + k]), kc = key_of(v[6 + k]);
-                uint64_t m = ka < kb ? ka : kb;
-                lo[k] = m < kc ? m : kc;
-                m = ka > kb ? ka : kb;
-                hi[k] = m > kc ? m : kc;
-            }
+            for (int k = 0; k < 3; k++) { lo[k] = r.lo[k]; hi[k] = r.hi[k]; }
 #pragma unroll
             for (int a = 0; a < 3; a++) {
                 const double cmin = value_of(nd.cbox[6 * (size_t)node + a]), cmax = value_of(nd.cbox[6 * (size_t)node + 3 + a]);
                 if (cmin == cmax) continue;                                   // bvh.hpp:252
                 const double scale = kBins / (cmax - cmin);
-                size_t b = static_cast<size_t>((C[3 * (size_t)t + a] - cmin) * scale);
+                size_t b = static_cast<size_t>((r.c[a] - cmin) * scale);
                 if (b > kBins - 1) b = kBins - 1;
                 bin[a] = (int)b;
             }
@@ -400,7 +425,7 @@ __global__ void plane_kernel(Nodes nd, Bins bins, uint32_t level_begin, uint32_t
 
 // "left" flags of the partition (bvh.hpp:131) with their exclusive prefix count inside
 // each chunk of kScanChunk positions; chunk totals go to `sums`.
-__global__ void flag_kernel(const double *__restrict__ C, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ node_of,
+__global__ void flag_kernel(const TriRec *__restrict__ T, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ node_of,
                             uint32_t n, Nodes nd, uint8_t *__restrict__ flag, uint32_t *__restrict__ local,
                             uint32_t *__restrict__ sums) {
     __shared__ uint32_t s_wave[kBlock / 64];
@@ -414,7 +439,7 @@ __global__ void flag_kernel(const double *__restrict__ C, const uint32_t *__rest
             const uint32_t node = node_of[p];
             if (node != kInactive) {
                 const int axis = nd.axis[node];
-                if (axis >= 0) f[k] = C[3 * (size_t)idx[p] + axis] < nd.pos[node] ? 1u : 0u;
+                if (axis >= 0) f[k] = T[idx[p]].c[axis] < nd.pos[node] ? 1u : 0u;
             }
         }
         mine += f[k];
@@ -683,7 +708,7 @@ __device__ __forceinline__ void wave_sync() {
 // `pos` inside the root's range when a partition moves it.  Pending nodes are kept in a
 // stack spread over the lanes' registers.  Node ids come from a block of 2m-2 ids reserved
 // for the root; ids left over are marked unused.
-__global__ __launch_bounds__(kBlock) void subtree_kernel(const double *__restrict__ V, const double *__restrict__ C,
+__global__ __launch_bounds__(kBlock) void subtree_kernel(const TriRec *__restrict__ T,
                                                          uint32_t *__restrict__ idx, const uint2 *__restrict__ small_list,
                                                          const uint32_t *__restrict__ need_local,
                                                          const uint32_t *__restrict__ need_sums, uint32_t n_small,
@@ -709,19 +734,13 @@ __global__ __launch_bounds__(kBlock) void subtree_kernel(const double *__restric
     for (int k = 0; k < 3; k++) { lo[k] = kKeyMinInit; hi[k] = kKeyMaxInit; }
     if (active) {
         tri = idx[f0 + lane];
-        const double *v = V + 9 * (size_t)tri;
+        const TriRec r = load_tri(T, tri);
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            const double a = v[k], b = v[3 + k], cc = v[6 + k];
-            const uint64_t ka = key_of(a), kb = key_of(b), kc = key_of(cc);
-            uint64_t t = ka < kb ? ka : kb;
-            lo[k] = t < kc ? t : kc;
-            t = ka > kb ? ka : kb;
-            hi[k] = t > kc ? t : kc;
-            if (a == 0.0) zinfo[k] = (1u << 1) | (uint32_t)(ka >> 63);
-            if (b == 0.0) zinfo[k] = (2u << 1) | (uint32_t)(kb >> 63);
-            if (cc == 0.0) zinfo[k] = (3u << 1) | (uint32_t)(kc >> 63);
-            c[k] = C[3 * (size_t)tri + k];
+            lo[k] = r.lo[k];
+            hi[k] = r.hi[k];
+            zinfo[k] = (r.zeros >> (3 * k)) & 7u;
+            c[k] = r.c[k];
         }
     }
 
@@ -1068,17 +1087,18 @@ int build_bvh_resident(const double *vertices, uint64_t n64, DeviceBvh *out, std
     delete out->impl;
     out->impl = new DeviceBvh::Impl;
     DeviceBuffers &buf = out->impl->buf;
-    // per triangle: 96 B of vertices and centroids, ~40 B of index arrays, 2.1 node records of 92 B,
+    // per triangle: 152 B of vertices and per-triangle records, ~40 B of index arrays, 2.1 node records of 92 B,
     // 136 B of output; per level node (n / 8 of them at most) 68 B of split data and 1248 B of bins
     HIP_TRY_B(buf.reserve((size_t)n * 700 + (16u << 20)));
-    double *V, *C;
+    double *V;
+    TriRec *T;
     uint32_t *idx[2], *node_of[2], *local, *sums, *holes, *fills, *starts;
     uint8_t *flag;
     uint2 *small_list;
     Counters *counters;
     Nodes nd;
     HIP_TRY_B(buf.get(&V, 9 * (size_t)n));
-    HIP_TRY_B(buf.get(&C, 3 * (size_t)n));
+    HIP_TRY_B(buf.get(&T, n));
     for (int k = 0; k < 2; k++) { HIP_TRY_B(buf.get(&idx[k], n)); HIP_TRY_B(buf.get(&node_of[k], n)); }
     HIP_TRY_B(buf.get(&local, n));
     HIP_TRY_B(buf.get(&sums, (size_t)chunks + 1));
@@ -1116,7 +1136,7 @@ int build_bvh_resident(const double *vertices, uint64_t n64, DeviceBvh *out, std
         HIP_TRY_B(hipMemcpyAsync(small_list, &root_entry, sizeof root_entry, hipMemcpyHostToDevice, stream));
     }
     HIP_TRY_B(hipMemcpyAsync(counters, &host_counters, sizeof host_counters, hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(centroid_kernel, dim3(pos_blocks), dim3(kBlock), 0, stream, V, C, idx[0], node_of[0], n, nd);
+    hipLaunchKernelGGL(centroid_kernel, dim3(pos_blocks), dim3(kBlock), 0, stream, V, T, idx[0], node_of[0], n, nd);
 
     Bins bins{nullptr, nullptr, nullptr};
     uint64_t bins_width = 0;
@@ -1130,7 +1150,7 @@ int build_bvh_resident(const double *vertices, uint64_t n64, DeviceBvh *out, std
         // one tile per block keeps more loads in flight.
         const uint32_t tiles_per_block = (level_end - level_begin) < 8 ? std::min<uint32_t>(std::max<uint32_t>(tiles / 256, 1), 8) : 1;
         const uint32_t fat_blocks = blocks_for(tiles, tiles_per_block);
-        hipLaunchKernelGGL(bounds_kernel, dim3(fat_blocks), dim3(kFat), 0, stream, V, C, idx[cur], node_of[cur], n, nd, tiles_per_block);
+        hipLaunchKernelGGL(bounds_kernel, dim3(fat_blocks), dim3(kFat), 0, stream, T, idx[cur], node_of[cur], n, nd, tiles_per_block);
         const uint32_t width = level_end - level_begin;
         if (width > bins_width) {
             bins_width = std::min<uint64_t>(std::max<uint64_t>(width, 2 * bins_width), top_cap);
@@ -1142,10 +1162,10 @@ int build_bvh_resident(const double *vertices, uint64_t n64, DeviceBvh *out, std
         HIP_TRY_B(hipMemsetAsync(bins.hi, 0x00, (size_t)width * kBinSlots * 3 * sizeof(uint64_t), stream));
         HIP_TRY_B(hipMemsetAsync(bins.cnt, 0x00, (size_t)width * kBinSlots * sizeof(uint32_t), stream));
         const uint32_t node_blocks = blocks_for(width);
-        hipLaunchKernelGGL(bin_kernel, dim3(fat_blocks), dim3(kFat), 0, stream, V, C, idx[cur], node_of[cur], n, nd, bins, level_begin,
+        hipLaunchKernelGGL(bin_kernel, dim3(fat_blocks), dim3(kFat), 0, stream, T, idx[cur], node_of[cur], n, nd, bins, level_begin,
                            tiles_per_block);
         hipLaunchKernelGGL(plane_kernel, dim3(node_blocks), dim3(kBlock), 0, stream, nd, bins, level_begin, level_end);
-        hipLaunchKernelGGL(flag_kernel, dim3(chunks), dim3(kBlock), 0, stream, C, idx[cur], node_of[cur], n, nd, flag, local, sums);
+        hipLaunchKernelGGL(flag_kernel, dim3(chunks), dim3(kBlock), 0, stream, T, idx[cur], node_of[cur], n, nd, flag, local, sums);
         hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, stream, sums, chunks);
         hipLaunchKernelGGL(split_kernel, dim3(node_blocks), dim3(kBlock), 0, stream, nd, pre, flag, level_begin, level_end, counters,
                            small_list, level);
@@ -1169,7 +1189,7 @@ int build_bvh_resident(const double *vertices, uint64_t n64, DeviceBvh *out, std
         hipLaunchKernelGGL(subtree_need_kernel, dim3(blocks_for(n_small)), dim3(kBlock), 0, stream, small_list, n_small, nd, local);
         hipLaunchKernelGGL(local_scan_kernel, dim3(small_chunks), dim3(kBlock), 0, stream, local, n_small, sums);
         hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, stream, sums, small_chunks);
-        hipLaunchKernelGGL(subtree_kernel, dim3(blocks_for(n_small, kBlock / 64)), dim3(kBlock), 0, stream, V, C, idx[cur], small_list,
+        hipLaunchKernelGGL(subtree_kernel, dim3(blocks_for(n_small, kBlock / 64)), dim3(kBlock), 0, stream, T, idx[cur], small_list,
                            local, sums, n_small, host_counters.next_id, nd, counters);
         uint32_t reserved = 0;
         HIP_TRY_B(hipMemcpyAsync(&reserved, sums + small_chunks, sizeof reserved, hipMemcpyDeviceToHost, stream));
