@@ -98,6 +98,7 @@ struct DevRender {
     int32_t w_inner, w_leaf, w_shade;   // weights of the wave's step choice
     int32_t tail_lanes;                 // at most this many live lanes: run every kind of step each round
     int32_t also_lanes;                 // a kind with at least this many waiting lanes runs in every round
+    int32_t also_leaf, also_shade;      // (inner node steps: also_lanes; triangle steps: also_leaf; shading: also_shade)
     unsigned long long *wave_log;       // diagnostics: {start, end} 100 MHz ticks per wave, or NULL
     unsigned long long *ticks;          // {earliest block start, latest block end} in 100 MHz ticks, or NULL
 };

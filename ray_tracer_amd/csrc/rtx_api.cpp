@@ -664,6 +664,8 @@ int rtx_render_device_timed(rtx_scene *sc, const rtx_render_params *p, void *d_r
     r.w_shade = knob("RTX_W_SHADE", 2);
     r.tail_lanes = knob("RTX_TAIL_LANES", 16);
     r.also_lanes = knob("RTX_ALSO_LANES", 24);
+    r.also_leaf = knob("RTX_ALSO_LEAF", 16);
+    r.also_shade = knob("RTX_ALSO_SHADE", r.also_lanes);
     if (r.w_inner < 1 || r.w_leaf < 1 || r.w_shade < 1) return fail(RTX_ERR_INVALID, "scheduler weights must be positive");
     if (r.W == 0 || r.H == 0 || r.owned_tiles == 0) return RTX_OK;
     DeviceGuard guard(sc->device);

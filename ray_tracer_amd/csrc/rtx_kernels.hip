@@ -332,7 +332,7 @@ struct Hot {
     const DevNode *nodes;
     const DevTri *tris;
     uint32_t n_point;
-    int32_t w_inner, w_leaf, w_shade, tail_lanes, also_lanes;
+    int32_t w_inner, w_leaf, w_shade, tail_lanes, also_lanes, also_leaf, also_shade;
 };
 
 __device__ __forceinline__ void start_query(Lane &L, const DevScene &sc, bool prune) {
@@ -644,7 +644,7 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
 
     // the stack of a lane is strided by the block size, a power of two: levels are shifted, not multiplied
     const uint32_t stride = 31u - (uint32_t)__builtin_clz(rp.stack_stride);
-    const Hot hot = {sc.nodes, sc.tris, sc.n_point, rp.w_inner, rp.w_leaf, rp.w_shade, rp.tail_lanes, rp.also_lanes};
+    const Hot hot = {sc.nodes, sc.tris, sc.n_point, rp.w_inner, rp.w_leaf, rp.w_shade, rp.tail_lanes, rp.also_lanes, rp.also_leaf, rp.also_shade};
     uint32_t *stack = lds + threadIdx.x;
     const Scratch scr = {rp.scratch_f64, rp.scratch_i32, rp.scratch_lanes, gw * 64u + lane};
     Counters c;
@@ -693,11 +693,11 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
             if (STATS && lane == 0) { rounds[0]++; lane_steps[0] += n_inner; }
             if (L.state == ST_INNER) inner_step<PRUNE, STATS>(L, hot, stack, stride, c);
         }
-        if (pick_leaf || (all_kinds && n_leaf) || n_leaf >= hot.also_lanes) {
+        if (pick_leaf || (all_kinds && n_leaf) || n_leaf >= hot.also_leaf) {
             if (STATS) { const int k = __popcll(__ballot(L.state == ST_LEAF)); if (lane == 0) { rounds[1]++; lane_steps[1] += k; } }
             if (L.state == ST_LEAF) leaf_step<PRUNE, STATS>(L, hot, stack, stride, c);
         }
-        if ((!pick_inner && !pick_leaf) || (all_kinds && n_shade) || n_shade >= hot.also_lanes) {
+        if ((!pick_inner && !pick_leaf) || (all_kinds && n_shade) || n_shade >= hot.also_shade) {
             if (STATS) { const int k = __popcll(__ballot(L.state == ST_SHADE)); if (lane == 0) { rounds[2]++; lane_steps[2] += k; } }
             if (L.state == ST_SHADE) shade_step<PRUNE, STATS>(L, acc, sc, rp, scr, c);
             // hand pixels to the lanes without one, in lane order

@@ -57,3 +57,9 @@ if "also" in exps:
     for t in (65, 48, 40, 32, 24, 16, 8):
         run(f"also_lanes={t}", {"RTX_ALSO_LANES": t})
     os.environ["RTX_ALSO_LANES"] = "65"
+if "also3" in exps:
+    for ai, al, ash in ((24, 24, 24), (24, 16, 24), (24, 12, 24), (24, 8, 24), (24, 24, 16), (24, 24, 12), (24, 16, 16), (32, 12, 16),
+                        (24, 12, 12), (32, 16, 24), (16, 12, 16), (24, 20, 32), (24, 16, 40)):
+        run(f"also inner/leaf/shade={ai}/{al}/{ash}", {"RTX_ALSO_LANES": ai, "RTX_ALSO_LEAF": al, "RTX_ALSO_SHADE": ash})
+    for k in ("RTX_ALSO_LANES", "RTX_ALSO_LEAF", "RTX_ALSO_SHADE"):
+        os.environ.pop(k, None)
