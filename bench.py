@@ -43,14 +43,16 @@ def cpu_baseline(scene_name, n_tris, W, H, depth, obj_path):
     scene_root = os.path.dirname(os.path.dirname(obj_path))
     try:
         if os.path.exists(ref):
-            cmd, kind = [ref, scene_name, scene_root, str(W), str(H), str(depth), "-", str(cores), "2"], "reference"
+            cmd, kind = [ref, scene_name, scene_root, str(W), str(H), str(depth), "-", str(cores), "3"], "reference"
         elif os.path.exists(cli):
-            cmd, kind = [cli, scene_name, obj_path, str(W), str(H), str(depth), "-", str(cores), "1", "1", "2"], "port"
+            cmd, kind = [cli, scene_name, obj_path, str(W), str(H), str(depth), "-", str(cores), "1", "1", "3"], "port"
         else:
             return None
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=900).stdout
         secs = [float(l.split()[1]) for l in out.splitlines() if l.startswith("frame_seconds")]
-        return {"kind": kind, "cores": cores, "seconds": min(secs), "frames": len(secs), "cmd": os.path.basename(cmd[0])}
+        # the reference times three frames in a row (src/main.cpp:42-61); the median one counts here
+        return {"kind": kind, "cores": cores, "seconds": sorted(secs)[len(secs) // 2], "all": secs, "frames": len(secs),
+                "cmd": os.path.basename(cmd[0])}
     except Exception as e:  # a missing baseline must not take the GPU number down with it
         return {"error": repr(e)}
 
@@ -77,7 +79,7 @@ def main():
                     help="gloo stages the tile gather through host memory: a rehearsal of the N > 1 path on a box with fewer "
                          "GPUs than ranks (every rank then renders on --device); never a benchmark")
     ap.add_argument("--device", type=int, default=None, help="HIP device ordinal (default LOCAL_RANK)")
-    ap.add_argument("--cpu-sample-div", type=int, default=2, help="CPU baseline renders (W/div) x (H/div)")
+    ap.add_argument("--cpu-sample-div", type=int, default=1, help="CPU baseline renders (W/div) x (H/div)")
     args = ap.parse_args()
 
     import numpy as np
@@ -317,8 +319,8 @@ def main():
                 "unit": "Mrays/s",
                 "cores": cb["cores"],
                 "kind": cb["kind"],
-                "sample": f"same scene and camera at {cw}x{ch} ({srays} rays), best of {cb['frames']} frames of "
-                          f"{cb['cmd']} with {cb['cores']} threads, {cb['seconds']:.3f} s",
+                "sample": f"same scene and camera at {cw}x{ch} ({srays} rays), median of {cb['frames']} frames "
+                          f"({', '.join('%.3f' % x for x in cb['all'])} s) of {cb['cmd']} with {cb['cores']} threads",
             }
         else:
             result["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port", "sample": repr(cb)}
