@@ -329,8 +329,9 @@ class HostScene:
             "colors": np.ctypeslib.as_array(d.colors, (n, 3)).copy(),
             "specularity": np.ctypeslib.as_array(d.specularity, (n,)).copy(),
             "reflectivity": np.ctypeslib.as_array(d.reflectivity, (n,)).copy(),
-            "nodes": np.frombuffer(C.string_at(d.nodes, m * 64), dtype=node_dt).copy(),
-            "indices": np.ctypeslib.as_array(d.indices, (n,)).copy(),
+            # a scene loaded without a tree has neither
+            "nodes": np.frombuffer(C.string_at(d.nodes, m * 64), dtype=node_dt).copy() if m else np.zeros(0, node_dt),
+            "indices": np.ctypeslib.as_array(d.indices, (n,)).copy() if m else np.zeros(0, np.uint64),
             "camera_position": np.array(d.camera_position[:]),
             "camera_rotation_deg": np.array(d.camera_rotation_deg[:]),
         }

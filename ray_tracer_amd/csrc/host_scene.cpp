@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <thread>
 
 namespace rtx {
@@ -19,18 +20,99 @@ namespace {
 
 const double kInf = std::numeric_limits<double>::infinity();
 
-bool slurp(const std::string &path, std::string *out) {
+// The whole file, NUL-terminated (strtod may look one character past the last number).
+struct FileText {
+    std::unique_ptr<char[]> data;
+    size_t size = 0;
+};
+
+bool slurp(const std::string &path, FileText *out) {
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return false;
     fseek(f, 0, SEEK_END);
     long sz = ftell(f);
     fseek(f, 0, SEEK_SET);
     if (sz < 0) { fclose(f); return false; }
-    out->resize(static_cast<size_t>(sz));
-    size_t got = sz ? fread(&(*out)[0], 1, static_cast<size_t>(sz), f) : 0;
+    out->data.reset(new char[static_cast<size_t>(sz) + 1]);
+    out->size = static_cast<size_t>(sz);
+    size_t got = sz ? fread(out->data.get(), 1, out->size, f) : 0;
+    out->data[out->size] = 0;
     fclose(f);
-    return got == static_cast<size_t>(sz);
+    return got == out->size;
 }
+
+// strtod for the decimal numbers OBJ files hold.  A literal of at most 19 significant digits whose
+// digit string w fits 2^53 and whose decimal exponent e is within +-22 is w * 10^e with both factors
+// exact doubles, so one IEEE multiplication or division rounds it correctly: the same bits as
+// strtod (and as the reference's `fs >> double`).  Everything else (longer literals, large
+// exponents, inf/nan, hex) goes to strtod itself.  Leading white space is skipped like strtod does.
+double scan_double(const char *p, char **end_out) {
+    static const double kPow10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                                      1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    const char *q = p;
+    while (*q == ' ' || (*q >= '\t' && *q <= '\r')) q++;
+    bool negative = false;
+    if (*q == '-' || *q == '+') negative = *q++ == '-';
+    uint64_t w = 0;
+    int digits = 0, exp10 = 0;
+    bool any = false;
+    for (; *q >= '0' && *q <= '9'; q++) {
+        any = true;
+        if (w || *q != '0') { w = w * 10 + static_cast<uint64_t>(*q - '0'); digits++; }
+    }
+    if (*q == '.') {
+        q++;
+        for (; *q >= '0' && *q <= '9'; q++) {
+            any = true;
+            if (w || *q != '0') { w = w * 10 + static_cast<uint64_t>(*q - '0'); digits++; }
+            exp10--;
+        }
+    }
+    if (!any || digits > 19 || *q == 'x' || *q == 'X') return strtod(p, end_out);
+    if (*q == 'e' || *q == 'E') {
+        const char *r = q + 1;
+        bool eneg = false;
+        if (*r == '-' || *r == '+') eneg = *r++ == '-';
+        if (*r >= '0' && *r <= '9') {
+            int e = 0;
+            for (; *r >= '0' && *r <= '9'; r++)
+                if (e < 10000) e = e * 10 + (*r - '0');
+            exp10 += eneg ? -e : e;
+            q = r;
+        }
+    }
+    if (w > (1ull << 53) || exp10 < -22 || exp10 > 22) return strtod(p, end_out);
+    double v = static_cast<double>(w);
+    v = exp10 < 0 ? v / kPow10[-exp10] : v * kPow10[exp10];
+    *end_out = const_cast<char *>(q);
+    return negative ? -v : v;
+}
+
+// strtoll(p, &end, 10) for literals of up to 18 digits; longer ones go to strtoll.
+long long scan_integer(const char *p, char **end_out) {
+    const char *q = p;
+    while (*q == ' ' || (*q >= '\t' && *q <= '\r')) q++;
+    bool negative = false;
+    if (*q == '-' || *q == '+') negative = *q++ == '-';
+    const char *first = q;
+    long long v = 0;
+    for (; *q >= '0' && *q <= '9'; q++) v = v * 10 + (*q - '0');
+    if (q == first || q - first > 18) return strtoll(p, end_out, 10);
+    *end_out = const_cast<char *>(q);
+    return negative ? -v : v;
+}
+
+// RTX_TIMING=1 prints how long each stage of a loader call took (stderr).
+struct StageClock {
+    const bool on = getenv("RTX_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[rtx timing] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
 
 // Threads for the host-side loops: OMP_NUM_THREADS when set (GPU boxes export their CPU share
 // there), else the hardware's count, never more than 16.
@@ -99,7 +181,7 @@ void parse_piece(const char *p, const char *const end, bool last_piece, ObjPiece
             if (fresh) {
                 for (double &c : xyz) {
                     char *q = nullptr;
-                    c = strtod(p, &q);
+                    c = scan_double(p, &q);
                     if (q == p || q > end) { out->err = "OBJ: vertex record is not 'v x y z'"; out->rc = RTX_ERR_UNSUPPORTED; return; }
                     p = q;
                 }
@@ -110,7 +192,7 @@ void parse_piece(const char *p, const char *const end, bool last_piece, ObjPiece
             if (fresh) {
                 for (long long &c : ijk) {
                     char *q = nullptr;
-                    c = strtoll(p, &q, 10);
+                    c = scan_integer(p, &q);
                     if (q == p || q > end) {
                         out->err = "OBJ: face record is not 'f i j k' (use the tolerant loader)";
                         out->rc = RTX_ERR_UNSUPPORTED;
@@ -141,7 +223,7 @@ void parse_piece_tolerant(const char *p, const char *const end, ObjPiece *out) {
             const char *q = p + 1;
             for (int k = 0; k < 3; k++) {
                 char *r = nullptr;
-                const double c = strtod(q, &r);
+                const double c = scan_double(q, &r);
                 if (r == q || r > next) { out->err = "OBJ: vertex record is not 'v x y z'"; out->rc = RTX_ERR_UNSUPPORTED; return; }
                 out->pos.push_back(c);
                 q = r;
@@ -150,7 +232,7 @@ void parse_piece_tolerant(const char *p, const char *const end, ObjPiece *out) {
             const char *q = p + 1;
             for (int k = 0; k < 3; k++) {
                 char *r = nullptr;
-                const long long c = strtoll(q, &r, 10);
+                const long long c = scan_integer(q, &r);
                 if (r == q || r > next) { out->err = "OBJ: face record has fewer than three vertices"; out->rc = RTX_ERR_UNSUPPORTED; return; }
                 q = r;
                 while (q < next && *q != ' ' && *q != '\t' && *q != '\n' && *q != '\r') q++;   // the /vt/vn part of the group
@@ -166,16 +248,18 @@ void parse_piece_tolerant(const char *p, const char *const end, ObjPiece *out) {
 // strict: the reference's grammar and its "vertex must be defined before the face" order;
 // otherwise the tolerant grammar, indices resolved against the whole vertex list.
 int load_obj_text(const std::string &path, bool strict, std::vector<double> *vertices9, std::string *err) {
-    std::string text;
+    StageClock clock;
+    FileText text;
     if (!slurp(path, &text)) { *err = "Failed to open file.\n"; return RTX_ERR_IO; }
+    clock.lap("read file");
     vertices9->clear();
-    const char *const begin = text.c_str();
-    const char *const end = begin + text.size();
+    const char *const begin = text.data.get();
+    const char *const end = begin + text.size;
     // piece boundaries: a few pieces per thread, at least 256 KiB each
-    const size_t want = std::max<size_t>(1, std::min<size_t>(4 * worker_threads(), text.size() / (1u << 18) + 1));
+    const size_t want = std::max<size_t>(1, std::min<size_t>(4 * worker_threads(), text.size / (1u << 18) + 1));
     std::vector<const char *> cut{begin};
     for (size_t k = 1; k < want; k++) {
-        const char *p = begin + text.size() / want * k;
+        const char *p = begin + text.size / want * k;
         if (p <= cut.back()) continue;
         while (p + 1 < end && !(p[0] == '\n' && (!strict || p[1] == 'v' || p[1] == 'f'))) p++;
         if (p + 1 >= end) break;
@@ -188,6 +272,7 @@ int load_obj_text(const std::string &path, bool strict, std::vector<double> *ver
         if (strict) parse_piece(cut[k], cut[k + 1], k + 1 == n_pieces, &pieces[k]);
         else parse_piece_tolerant(cut[k], cut[k + 1], &pieces[k]);
     });
+    clock.lap("tokenise pieces");
     for (const ObjPiece &pc : pieces)
         if (pc.rc != RTX_OK) { *err = pc.err; return pc.rc; }
     // global vertex list, face offsets
@@ -201,7 +286,9 @@ int load_obj_text(const std::string &path, bool strict, std::vector<double> *ver
     parallel_for(n_pieces, [&](size_t k) {
         if (!pieces[k].pos.empty()) memcpy(&pos[3 * v_before[k]], pieces[k].pos.data(), pieces[k].pos.size() * sizeof(double));
     });
+    clock.lap("join vertex lists");
     vertices9->resize(9 * f_before[n_pieces]);
+    clock.lap("allocate triangles");
     std::vector<int> bad(n_pieces, 0);
     parallel_for(n_pieces, [&](size_t k) {
         const std::vector<long long> &f = pieces[k].faces;
@@ -219,6 +306,7 @@ int load_obj_text(const std::string &path, bool strict, std::vector<double> *ver
             }
         }
     });
+    clock.lap("resolve faces");
     for (int b : bad)
         if (b) {
             *err = strict ? "OBJ: face references a vertex that is not defined yet" : "OBJ: face references a vertex that does not exist";

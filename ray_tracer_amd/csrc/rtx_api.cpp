@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -65,6 +66,20 @@ int fail(int code, const std::string &msg) {
         hipError_t e_ = (expr);                                                                        \
         if (e_ != hipSuccess) return fail(RTX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
+
+// No exception leaves the library: the body of an entry point that allocates runs in here.
+template <typename F>
+int guarded(F &&body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return fail(RTX_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception &e) {
+        return fail(RTX_ERR_INVALID, std::string("unexpected failure: ") + e.what());
+    } catch (...) {
+        return fail(RTX_ERR_INVALID, "unexpected failure");
+    }
+}
 
 // Selects a device for the current scope and puts the previous one back.
 struct DeviceGuard {
@@ -227,22 +242,21 @@ const char *rtx_last_error(void) { return g_error.c_str(); }
 const char *rtx_version(void) { return "rtx-mi355x 0.1 (gfx950)"; }
 
 // ------------------------------------------------------------------ host scenes
-int rtx_host_scene_load_obj_ex(const char *obj_path, const char *preset, uint32_t flags, int32_t device, rtx_host_scene **out) {
+static int host_scene_load_obj_ex_impl(const char *obj_path, const char *preset, uint32_t flags, int32_t device, rtx_host_scene **out) {
     if (!obj_path || !preset || !out) return fail(RTX_ERR_INVALID, "NULL argument");
     *out = nullptr;
     const int verbose = (flags & RTX_LOAD_VERBOSE) != 0;
-    rtx_host_scene *hs = new (std::nothrow) rtx_host_scene;
-    if (!hs) return fail(RTX_ERR_NOMEM, "out of host memory");
+    std::unique_ptr<rtx_host_scene> hs(new rtx_host_scene);
     std::string err;
     int rc = (flags & RTX_LOAD_TOLERANT) ? rtx::parse_obj_tolerant(obj_path, &hs->s.vertices, &err)
                                          : rtx::parse_obj(obj_path, &hs->s.vertices, &err);
     // Scene::parseOBJ prints the face count (scene.hpp:248)
     if (rc == RTX_OK && verbose) printf("[ TRI ] %zu triangles.\n", hs->s.vertices.size() / 9);
     if (rc == RTX_OK) rc = rtx::apply_preset(&hs->s, preset, &err);
-    if (rc != RTX_OK) { delete hs; return fail(rc, err); }
-    rc = finish_host_scene(hs, false, false, verbose, loader_builder(flags), device);
-    if (rc != RTX_OK) { delete hs; return rc; }
-    *out = hs;
+    if (rc != RTX_OK) return fail(rc, err);
+    rc = finish_host_scene(hs.get(), false, false, verbose, loader_builder(flags), device);
+    if (rc != RTX_OK) return rc;
+    *out = hs.release();
     return RTX_OK;
 }
 
@@ -250,7 +264,7 @@ int rtx_host_scene_load_obj(const char *obj_path, const char *preset, int verbos
     return rtx_host_scene_load_obj_ex(obj_path, preset, verbose ? RTX_LOAD_VERBOSE : 0, -1, out);
 }
 
-int rtx_host_scene_standin_ex(const char *preset, uint64_t n_triangles, uint64_t seed, const char *obj_path_out, uint32_t flags,
+static int host_scene_standin_ex_impl(const char *preset, uint64_t n_triangles, uint64_t seed, const char *obj_path_out, uint32_t flags,
                               int32_t device, rtx_host_scene **out) {
     if (!preset) return fail(RTX_ERR_INVALID, "NULL preset");
     if (out) *out = nullptr;
@@ -262,16 +276,15 @@ int rtx_host_scene_standin_ex(const char *preset, uint64_t n_triangles, uint64_t
     if (obj_path_out)
         if (int rc = rtx::write_obj(obj_path_out, verts, faces, &err)) return fail(rc, err);
     if (!out) return RTX_OK;
-    rtx_host_scene *hs = new (std::nothrow) rtx_host_scene;
-    if (!hs) return fail(RTX_ERR_NOMEM, "out of host memory");
+    std::unique_ptr<rtx_host_scene> hs(new rtx_host_scene);
     hs->s.vertices.reserve(faces.size() * 3);
     for (uint32_t v : faces) hs->s.vertices.insert(hs->s.vertices.end(), &verts[3 * (size_t)v], &verts[3 * (size_t)v] + 3);
     if (verbose) printf("[ TRI ] %zu triangles.\n", hs->s.vertices.size() / 9);
     int rc = rtx::apply_preset(&hs->s, preset, &err);
-    if (rc != RTX_OK) { delete hs; return fail(rc, err); }
-    rc = finish_host_scene(hs, false, false, verbose, loader_builder(flags), device);
-    if (rc != RTX_OK) { delete hs; return rc; }
-    *out = hs;
+    if (rc != RTX_OK) return fail(rc, err);
+    rc = finish_host_scene(hs.get(), false, false, verbose, loader_builder(flags), device);
+    if (rc != RTX_OK) return rc;
+    *out = hs.release();
     return RTX_OK;
 }
 
@@ -280,7 +293,7 @@ int rtx_host_scene_standin(const char *preset, uint64_t n_triangles, uint64_t se
     return rtx_host_scene_standin_ex(preset, n_triangles, seed, obj_path_out, verbose ? RTX_LOAD_VERBOSE : 0, -1, out);
 }
 
-int rtx_host_scene_from_desc(const rtx_scene_desc *d, rtx_host_scene **out) {
+static int host_scene_from_desc_impl(const rtx_scene_desc *d, rtx_host_scene **out) {
     if (!d || !out) return fail(RTX_ERR_INVALID, "NULL argument");
     *out = nullptr;
     const uint64_t n = d->n_triangles;
@@ -290,8 +303,7 @@ int rtx_host_scene_from_desc(const rtx_scene_desc *d, rtx_host_scene **out) {
     if ((d->n_point_lights && !d->point_lights) || (d->n_directional_lights && !d->directional_lights)) return fail(RTX_ERR_INVALID, "light arrays missing");
     const bool have_bvh = d->n_nodes != 0 || d->nodes || d->indices;
     if (have_bvh && (!d->nodes || !d->indices || d->n_nodes == 0 || d->n_nodes > 2 * n - 1)) return fail(RTX_ERR_INVALID, "BVH arrays incomplete");
-    rtx_host_scene *hs = new (std::nothrow) rtx_host_scene;
-    if (!hs) return fail(RTX_ERR_NOMEM, "out of host memory");
+    std::unique_ptr<rtx_host_scene> hs(new rtx_host_scene);
     rtx::HostScene &s = hs->s;
     s.vertices.assign(d->vertices, d->vertices + 9 * n);
     if (d->normals) s.normals.assign(d->normals, d->normals + 3 * n);
@@ -311,9 +323,9 @@ int rtx_host_scene_from_desc(const rtx_scene_desc *d, rtx_host_scene **out) {
     s.ambient = d->ambient;
     s.point_lights.assign(d->point_lights, d->point_lights + d->n_point_lights);
     s.directional_lights.assign(d->directional_lights, d->directional_lights + d->n_directional_lights);
-    int rc = finish_host_scene(hs, d->normals != nullptr, have_bvh, 0);
-    if (rc != RTX_OK) { delete hs; return rc; }
-    *out = hs;
+    int rc = finish_host_scene(hs.get(), d->normals != nullptr, have_bvh, 0);
+    if (rc != RTX_OK) return rc;
+    *out = hs.release();
     return RTX_OK;
 }
 
@@ -353,7 +365,7 @@ int rtx_host_scene_set_camera(rtx_host_scene *hs, const double position[3], cons
     return RTX_OK;
 }
 
-int rtx_host_scene_set_lights(rtx_host_scene *hs, double ambient, uint32_t n_point, const rtx_light *point,
+static int host_scene_set_lights_impl(rtx_host_scene *hs, double ambient, uint32_t n_point, const rtx_light *point,
                               uint32_t n_directional, const rtx_light *directional) {
     if (!hs || (n_point && !point) || (n_directional && !directional)) return fail(RTX_ERR_INVALID, "NULL argument");
     hs->s.ambient = ambient;
@@ -365,7 +377,7 @@ int rtx_host_scene_set_lights(rtx_host_scene *hs, double ambient, uint32_t n_poi
 void rtx_host_scene_free(rtx_host_scene *hs) { delete hs; }
 
 // ------------------------------------------------------------------ BVH build
-int rtx_bvh_build(const double *vertices, uint64_t n, int32_t builder, int32_t device, rtx_bvh_node *nodes_out,
+static int bvh_build_impl(const double *vertices, uint64_t n, int32_t builder, int32_t device, rtx_bvh_node *nodes_out,
                   uint64_t *indices_out, uint64_t *n_nodes_out, int32_t *depth_out, double *seconds_out) {
     if (!vertices || !nodes_out || !indices_out || !n_nodes_out) return fail(RTX_ERR_INVALID, "NULL argument");
     if (n == 0) return fail(RTX_ERR_INVALID, "cannot build a BVH over zero triangles");
@@ -398,7 +410,7 @@ int rtx_bvh_build(const double *vertices, uint64_t n, int32_t builder, int32_t d
     return RTX_OK;
 }
 
-int rtx_host_scene_rebuild_bvh(rtx_host_scene *hs, int32_t builder, int32_t device, double *seconds_out) {
+static int host_scene_rebuild_bvh_impl(rtx_host_scene *hs, int32_t builder, int32_t device, double *seconds_out) {
     if (!hs) return fail(RTX_ERR_INVALID, "NULL argument");
     std::string err;
     if (int rc = build_into_host_scene(hs->s, builder, device, &err)) return fail(rc, err);
@@ -408,8 +420,9 @@ int rtx_host_scene_rebuild_bvh(rtx_host_scene *hs, int32_t builder, int32_t devi
 
 // ------------------------------------------------------------------ device scenes
 static int create_scene_built_on_device(const rtx_scene_desc *d, rtx_scene **out);
+struct SceneDeleter { void operator()(rtx_scene *sc) const { rtx_scene_destroy(sc); } };
 
-int rtx_scene_create_from_host(const rtx_host_scene *hs, int32_t device, rtx_scene **out) {
+static int scene_create_from_host_impl(const rtx_host_scene *hs, int32_t device, rtx_scene **out) {
     if (!hs || !out) return fail(RTX_ERR_INVALID, "NULL argument");
     *out = nullptr;
     const rtx::HostScene &s = hs->s;
@@ -473,8 +486,8 @@ int rtx_scene_create_from_host(const rtx_host_scene *hs, int32_t device, rtx_sce
     }
     DeviceGuard guard(device);
     if (!guard.ok) return fail(RTX_ERR_DEVICE, "cannot select the device");
-    rtx_scene *sc = new (std::nothrow) rtx_scene;
-    if (!sc) return fail(RTX_ERR_NOMEM, "out of host memory");
+    std::unique_ptr<rtx_scene, SceneDeleter> owner(new rtx_scene);
+    rtx_scene *sc = owner.get();
     sc->device = device;
     auto upload = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
@@ -485,10 +498,7 @@ int rtx_scene_create_from_host(const rtx_host_scene *hs, int32_t device, rtx_sce
     hipError_t e = upload(&sc->d_nodes, nodes.data(), nodes.size() * sizeof(rtx::DevNode));
     if (e == hipSuccess) e = upload(&sc->d_tris, tris.data(), n * sizeof(rtx::DevTri));
     if (e == hipSuccess) e = upload(&sc->d_mats, mats.data(), n * sizeof(rtx::DevMat));
-    if (e != hipSuccess) {
-        rtx_scene_destroy(sc);
-        return fail(RTX_ERR_DEVICE, std::string("scene upload: ") + hipGetErrorString(e));
-    }
+    if (e != hipSuccess) return fail(RTX_ERR_DEVICE, std::string("scene upload: ") + hipGetErrorString(e));
     auto tame = [](double v) { return v == 0.0 || (std::fabs(v) >= 0x1p-300 && std::fabs(v) <= 0x1p300); };
     bool boxes_tame = true;
     for (const rtx_bvh_node &h : s.nodes)
@@ -498,11 +508,8 @@ int rtx_scene_create_from_host(const rtx_host_scene *hs, int32_t device, rtx_sce
     const SceneCommon common{s.viewport, s.camera_position, s.camera_rotation_deg, s.background, s.ambient,
                              s.point_lights.data(), (uint32_t)s.point_lights.size(),
                              s.directional_lights.data(), (uint32_t)s.directional_lights.size()};
-    if (int rc = finish_device_scene(sc, common, n, m, root_box, boxes_tame, s.bvh_depth)) {
-        rtx_scene_destroy(sc);
-        return rc;
-    }
-    *out = sc;
+    if (int rc = finish_device_scene(sc, common, n, m, root_box, boxes_tame, s.bvh_depth)) return rc;
+    *out = owner.release();
     return RTX_OK;
 }
 
@@ -528,8 +535,8 @@ static int create_scene_built_on_device(const rtx_scene_desc *d, rtx_scene **out
     const uint64_t m = bvh.n_nodes;
     if (m + 1 >= (1ull << 28)) return fail(RTX_ERR_UNSUPPORTED, "more than 2^28 triangles or BVH nodes");
 
-    rtx_scene *sc = new (std::nothrow) rtx_scene;
-    if (!sc) return fail(RTX_ERR_NOMEM, "out of host memory");
+    std::unique_ptr<rtx_scene, SceneDeleter> owner(new rtx_scene);
+    rtx_scene *sc = owner.get();
     sc->device = device;
     struct Temp { void *p = nullptr; ~Temp() { (void)hipFree(p); } } t_normals, t_colors, t_spec, t_refl;
     auto stage = [&](Temp &t, const void *src, size_t bytes) -> hipError_t {
@@ -543,43 +550,34 @@ static int create_scene_built_on_device(const rtx_scene_desc *d, rtx_scene **out
     if (e == hipSuccess) e = stage(t_colors, d->colors, 3 * n * sizeof(int32_t));
     if (e == hipSuccess) e = stage(t_spec, d->specularity, n * sizeof(int32_t));
     if (e == hipSuccess) e = stage(t_refl, d->reflectivity, n * sizeof(double));
-    if (e != hipSuccess) {
-        rtx_scene_destroy(sc);
-        return fail(RTX_ERR_DEVICE, std::string("scene upload: ") + hipGetErrorString(e));
-    }
+    if (e != hipSuccess) return fail(RTX_ERR_DEVICE, std::string("scene upload: ") + hipGetErrorString(e));
     sc->bytes = (m + 1) * sizeof(rtx::DevNode) + n * (sizeof(rtx::DevTri) + sizeof(rtx::DevMat));
     int32_t boxes_tame = 0;
     double root_box[6];
     int rc = rtx::flatten_scene_device(bvh, (const double *)t_normals.p, (const int32_t *)t_colors.p, (const int32_t *)t_spec.p,
                                        (const double *)t_refl.p, (rtx::DevNode *)sc->d_nodes, (rtx::DevTri *)sc->d_tris,
                                        (rtx::DevMat *)sc->d_mats, &boxes_tame, root_box, &err);
-    if (rc != RTX_OK) {
-        rtx_scene_destroy(sc);
-        return fail(rc, err);
-    }
+    if (rc != RTX_OK) return fail(rc, err);
     const SceneCommon common{d->viewport, d->camera_position, d->camera_rotation_deg, d->background, d->ambient,
                              d->point_lights, d->n_point_lights, d->directional_lights, d->n_directional_lights};
     rc = finish_device_scene(sc, common, n, m, root_box, boxes_tame != 0, bvh.depth);
-    if (rc != RTX_OK) {
-        rtx_scene_destroy(sc);
-        return rc;
-    }
+    if (rc != RTX_OK) return rc;
     sc->build_seconds = bvh.device_ms * 1e-3;
-    *out = sc;
+    *out = owner.release();
     return RTX_OK;
 }
 
-int rtx_scene_create_with_builder(const rtx_scene_desc *desc, int32_t builder, rtx_scene **out) {
+static int scene_create_with_builder_impl(const rtx_scene_desc *desc, int32_t builder, rtx_scene **out) {
     if (!desc || !out) return fail(RTX_ERR_INVALID, "NULL argument");
     *out = nullptr;
     const bool have_bvh = desc->n_nodes != 0 || desc->nodes || desc->indices;
     if (builder != RTX_BUILDER_HOST && builder != RTX_BUILDER_DEVICE) return fail(RTX_ERR_INVALID, "unknown BVH builder");
     if (!have_bvh && builder == RTX_BUILDER_DEVICE) return create_scene_built_on_device(desc, out);
-    rtx_host_scene *hs = nullptr;
-    if (int rc = rtx_host_scene_from_desc(desc, &hs)) return rc;
-    int rc = rtx_scene_create_from_host(hs, desc->device, out);
+    rtx_host_scene *raw = nullptr;
+    if (int rc = rtx_host_scene_from_desc(desc, &raw)) return rc;
+    std::unique_ptr<rtx_host_scene> hs(raw);
+    int rc = rtx_scene_create_from_host(hs.get(), desc->device, out);
     if (rc == RTX_OK && !have_bvh) (*out)->build_seconds = hs->s.bvh_seconds;
-    rtx_host_scene_free(hs);
     return rc;
 }
 
@@ -635,7 +633,7 @@ int rtx_render_device(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8,
     return rtx_render_device_timed(sc, p, d_rgb_u8, d_hit_id, d_rgb_i32, d_t, d_stats, nullptr, stream);
 }
 
-int rtx_render_device_timed(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id, void *d_rgb_i32, void *d_t,
+static int render_device_timed_impl(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id, void *d_rgb_i32, void *d_t,
                             void *d_stats, void *d_ticks, void *stream) {
     if (!sc) return fail(RTX_ERR_INVALID, "scene is NULL");
     ResolvedParams rp;
@@ -778,7 +776,7 @@ int rtx_render_device_timed(rtx_scene *sc, const rtx_render_params *p, void *d_r
     return RTX_OK;
 }
 
-int rtx_render(rtx_scene *sc, const rtx_render_params *p, uint8_t *rgb_out, int32_t *hit_id_out, rtx_stats *stats) {
+static int render_impl(rtx_scene *sc, const rtx_render_params *p, uint8_t *rgb_out, int32_t *hit_id_out, rtx_stats *stats) {
     if (!sc) return fail(RTX_ERR_INVALID, "scene is NULL");
     if (!rgb_out) return fail(RTX_ERR_INVALID, "rgb_out is NULL");
     const uint64_t px = rtx_output_pixels(p);
@@ -843,7 +841,7 @@ int rtx_untile(const rtx_render_params *p, int32_t n_ranks, const void *d_gather
     return RTX_OK;
 }
 
-int rtx_selftest_pow(uint64_t n, uint64_t seed, uint64_t *differing, uint64_t *max_ulps) {
+static int selftest_pow_impl(uint64_t n, uint64_t seed, uint64_t *differing, uint64_t *max_ulps) {
     if (!differing || !max_ulps) return fail(RTX_ERR_INVALID, "NULL argument");
     *differing = 0;
     *max_ulps = 0;
@@ -909,7 +907,7 @@ int rtx_save_ppm(const char *path, int32_t width, int32_t height, const uint8_t 
 
 // The same canvas as a PNG (8-bit RGB, rows unfiltered, deflate "stored" blocks: no compression
 // library needed and nothing to get wrong; a 4K frame is 24.9 MB either way).
-int rtx_save_png(const char *path, int32_t width, int32_t height, const uint8_t *rgb) {
+static int save_png_impl(const char *path, int32_t width, int32_t height, const uint8_t *rgb) {
     if (!path || !rgb || width <= 0 || height <= 0) return fail(RTX_ERR_INVALID, "bad argument");
     FILE *f = fopen(path, "wb");
     if (!f) return fail(RTX_ERR_IO, "Failed to open file.\n");
@@ -978,6 +976,59 @@ int rtx_save_png(const char *path, int32_t width, int32_t height, const uint8_t 
     chunk("IEND", {});
     if (fclose(f) != 0 || !ok) return fail(RTX_ERR_IO, "short write");
     return RTX_OK;
+}
+
+// ------------------------------------------------------------------ guarded entry points
+int rtx_host_scene_load_obj_ex(const char *obj_path, const char *preset, uint32_t flags, int32_t device, rtx_host_scene **out) {
+    return guarded([&]() -> int { return host_scene_load_obj_ex_impl(obj_path, preset, flags, device, out); });
+}
+
+int rtx_host_scene_standin_ex(const char *preset, uint64_t n_triangles, uint64_t seed, const char *obj_path_out, uint32_t flags,
+                              int32_t device, rtx_host_scene **out) {
+    return guarded([&]() -> int { return host_scene_standin_ex_impl(preset, n_triangles, seed, obj_path_out, flags, device, out); });
+}
+
+int rtx_host_scene_from_desc(const rtx_scene_desc *d, rtx_host_scene **out) {
+    return guarded([&]() -> int { return host_scene_from_desc_impl(d, out); });
+}
+
+int rtx_host_scene_set_lights(rtx_host_scene *hs, double ambient, uint32_t n_point, const rtx_light *point,
+                              uint32_t n_directional, const rtx_light *directional) {
+    return guarded([&]() -> int { return host_scene_set_lights_impl(hs, ambient, n_point, point, n_directional, directional); });
+}
+
+int rtx_bvh_build(const double *vertices, uint64_t n, int32_t builder, int32_t device, rtx_bvh_node *nodes_out,
+                  uint64_t *indices_out, uint64_t *n_nodes_out, int32_t *depth_out, double *seconds_out) {
+    return guarded([&]() -> int { return bvh_build_impl(vertices, n, builder, device, nodes_out, indices_out, n_nodes_out, depth_out, seconds_out); });
+}
+
+int rtx_host_scene_rebuild_bvh(rtx_host_scene *hs, int32_t builder, int32_t device, double *seconds_out) {
+    return guarded([&]() -> int { return host_scene_rebuild_bvh_impl(hs, builder, device, seconds_out); });
+}
+
+int rtx_scene_create_from_host(const rtx_host_scene *hs, int32_t device, rtx_scene **out) {
+    return guarded([&]() -> int { return scene_create_from_host_impl(hs, device, out); });
+}
+
+int rtx_scene_create_with_builder(const rtx_scene_desc *desc, int32_t builder, rtx_scene **out) {
+    return guarded([&]() -> int { return scene_create_with_builder_impl(desc, builder, out); });
+}
+
+int rtx_render_device_timed(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id, void *d_rgb_i32, void *d_t,
+                            void *d_stats, void *d_ticks, void *stream) {
+    return guarded([&]() -> int { return render_device_timed_impl(sc, p, d_rgb_u8, d_hit_id, d_rgb_i32, d_t, d_stats, d_ticks, stream); });
+}
+
+int rtx_render(rtx_scene *sc, const rtx_render_params *p, uint8_t *rgb_out, int32_t *hit_id_out, rtx_stats *stats) {
+    return guarded([&]() -> int { return render_impl(sc, p, rgb_out, hit_id_out, stats); });
+}
+
+int rtx_selftest_pow(uint64_t n, uint64_t seed, uint64_t *differing, uint64_t *max_ulps) {
+    return guarded([&]() -> int { return selftest_pow_impl(n, seed, differing, max_ulps); });
+}
+
+int rtx_save_png(const char *path, int32_t width, int32_t height, const uint8_t *rgb) {
+    return guarded([&]() -> int { return save_png_impl(path, width, height, rgb); });
 }
 
 }  // extern "C"

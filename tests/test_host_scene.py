@@ -191,6 +191,39 @@ def test_tolerant_loader_errors(tmp_path):
         rt.HostScene.load_obj(str(tmp_path / "missing.obj"), "teapot", tolerant=True)
 
 
+def test_number_literals_read_like_strtod(tmp_path):
+    """Scene::parseOBJ reads coordinates with `fs >> double` (scene.hpp:229-231): correctly rounded, as
+    Python's float().  Short literals take the loaders' own conversion, long or extreme ones strtod."""
+    import random
+    rnd = random.Random(5)
+
+    def literal():
+        k = rnd.random()
+        if k < 0.30: return "%.6f" % rnd.uniform(-100, 100)
+        if k < 0.40: return repr(rnd.uniform(-1, 1))
+        if k < 0.50: return "%d" % rnd.randint(-1000, 1000)
+        if k < 0.60: return "%.3e" % rnd.uniform(-1e5, 1e5)
+        if k < 0.65: return "%.17g" % rnd.uniform(-1e-3, 1e-3)
+        if k < 0.70: return "%dE%+d" % (rnd.randint(0, 10 ** 15), rnd.randint(-30, 30))
+        if k < 0.75: return "." + str(rnd.randint(0, 10 ** 9))
+        if k < 0.80: return str(rnd.randint(0, 999)) + "."
+        if k < 0.85: return "%.25f" % rnd.uniform(-3, 3)
+        if k < 0.90: return "-0.0"
+        if k < 0.95: return "+%d.%020d" % (rnd.randint(0, 99), rnd.randint(0, 10 ** 20 - 1))
+        return "0.%s" % ("0" * rnd.randint(0, 30) + str(rnd.randint(1, 10 ** 6)))
+
+    n = 6000
+    lits = [[literal() for _ in range(3)] for _ in range(n)]
+    path = tmp_path / "literals.obj"
+    path.write_text("".join("v %s %s %s\n" % tuple(a) for a in lits) +
+                    "\n".join("f %d %d %d" % (i + 1, i + 2, i + 3) for i in range(0, n - 2, 3)))
+    want = np.array([float(x) for i in range(0, n - 2, 3) for k in range(3) for x in lits[i + k]])
+    for tolerant in (False, True):
+        got = rt.HostScene.load_obj(str(path), "teapot", tolerant=tolerant, no_bvh=True).arrays()["vertices"]
+        assert got.size == want.size
+        assert got.tobytes() == want.tobytes()        # bit for bit, signed zeros included
+
+
 @pytest.mark.parametrize("w,h", [(1, 1), (7, 5), (300, 217), (1920, 37)])
 def test_png_writer_round_trips(tmp_path, w, h):
     """Decoded with zlib and struct only: signature, IHDR, one IDAT of stored blocks, IEND, every CRC."""
