@@ -14,30 +14,59 @@
 #include <memory>
 #include <thread>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 namespace rtx {
 
 namespace {
 
 const double kInf = std::numeric_limits<double>::infinity();
 
-// The whole file, NUL-terminated (strtod may look one character past the last number).
+// The whole file, NUL-terminated (strtod may look one character past the last number).  Mapped
+// when the size leaves room for the terminator in the last page (the kernel zero-fills it),
+// read into a buffer otherwise.
 struct FileText {
-    std::unique_ptr<char[]> data;
+    const char *data = nullptr;
     size_t size = 0;
+    void *mapping = nullptr;
+    size_t mapped = 0;
+    std::unique_ptr<char[]> buffer;
+    FileText() = default;
+    FileText(const FileText &) = delete;
+    FileText &operator=(const FileText &) = delete;
+    ~FileText() { if (mapping) munmap(mapping, mapped); }
 };
 
 bool slurp(const std::string &path, FileText *out) {
-    FILE *f = fopen(path.c_str(), "rb");
-    if (!f) return false;
-    fseek(f, 0, SEEK_END);
-    long sz = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    if (sz < 0) { fclose(f); return false; }
-    out->data.reset(new char[static_cast<size_t>(sz) + 1]);
-    out->size = static_cast<size_t>(sz);
-    size_t got = sz ? fread(out->data.get(), 1, out->size, f) : 0;
-    out->data[out->size] = 0;
-    fclose(f);
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 0) { close(fd); return false; }
+    out->size = static_cast<size_t>(st.st_size);
+    const size_t page = static_cast<size_t>(sysconf(_SC_PAGESIZE));
+    if (out->size && out->size % page != 0) {
+        void *m = mmap(nullptr, out->size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+        if (m != MAP_FAILED) {
+            out->mapping = m;
+            out->mapped = out->size;
+            out->data = static_cast<const char *>(m);
+            close(fd);
+            return true;
+        }
+    }
+    out->buffer.reset(new char[out->size + 1]);
+    size_t got = 0;
+    while (got < out->size) {
+        const ssize_t k = read(fd, out->buffer.get() + got, out->size - got);
+        if (k <= 0) break;
+        got += static_cast<size_t>(k);
+    }
+    close(fd);
+    out->buffer[out->size] = 0;
+    out->data = out->buffer.get();
     return got == out->size;
 }
 
@@ -247,13 +276,13 @@ void parse_piece_tolerant(const char *p, const char *const end, ObjPiece *out) {
 // Tokenises the file in pieces on the worker threads and assembles 9 doubles per face.
 // strict: the reference's grammar and its "vertex must be defined before the face" order;
 // otherwise the tolerant grammar, indices resolved against the whole vertex list.
-int load_obj_text(const std::string &path, bool strict, std::vector<double> *vertices9, std::string *err) {
+int load_obj_text(const std::string &path, bool strict, Doubles *vertices9, std::string *err) {
     StageClock clock;
     FileText text;
     if (!slurp(path, &text)) { *err = "Failed to open file.\n"; return RTX_ERR_IO; }
     clock.lap("read file");
     vertices9->clear();
-    const char *const begin = text.data.get();
+    const char *const begin = text.data;
     const char *const end = begin + text.size;
     // piece boundaries: a few pieces per thread, at least 256 KiB each
     const size_t want = std::max<size_t>(1, std::min<size_t>(4 * worker_threads(), text.size / (1u << 18) + 1));
@@ -282,7 +311,7 @@ int load_obj_text(const std::string &path, bool strict, std::vector<double> *ver
         f_before[k + 1] = f_before[k] + pieces[k].faces.size() / 4;
     }
     const long long n_vertices = static_cast<long long>(v_before[n_pieces]);
-    std::vector<double> pos(3 * v_before[n_pieces]);
+    Doubles pos(3 * v_before[n_pieces]);
     parallel_for(n_pieces, [&](size_t k) {
         if (!pieces[k].pos.empty()) memcpy(&pos[3 * v_before[k]], pieces[k].pos.data(), pieces[k].pos.size() * sizeof(double));
     });
@@ -318,7 +347,7 @@ int load_obj_text(const std::string &path, bool strict, std::vector<double> *ver
 
 }  // namespace
 
-int parse_obj(const std::string &path, std::vector<double> *vertices9, std::string *err) {
+int parse_obj(const std::string &path, Doubles *vertices9, std::string *err) {
     return load_obj_text(path, true, vertices9, err);
 }
 
@@ -326,20 +355,20 @@ int parse_obj(const std::string &path, std::vector<double> *vertices9, std::stri
 // keeps the lines whose first token is `v` or `f`, writes the vertices first and rewrites
 // each face as `f i0 i1 i2` from the leading integer of its first three index groups,
 // resolving negative indices against the number of vertices in the whole file.
-int parse_obj_tolerant(const std::string &path, std::vector<double> *vertices9, std::string *err) {
+int parse_obj_tolerant(const std::string &path, Doubles *vertices9, std::string *err) {
     return load_obj_text(path, false, vertices9, err);
 }
 
-// Triangle::Triangle, include/triangle.hpp:16-25.
+// Triangle::Triangle, include/triangle.hpp:16-25: the normal (the centroid, which only the host
+// BVH builder reads, is computed by fill_centroids when that builder runs).
 void setup_triangles(HostScene *hs, bool have_normals) {
+    if (have_normals) return;
     const uint64_t n = hs->n_triangles();
-    if (!have_normals) hs->normals.resize(3 * n);
-    hs->centroids.resize(3 * n);
-    const uint64_t per = 1u << 16;
+    hs->normals.resize(3 * n);
+    const uint64_t per = 1u << 15;
     parallel_for((n + per - 1) / per, [&](size_t chunk) {
-    for (uint64_t i = chunk * per; i < std::min<uint64_t>(n, (chunk + 1) * per); i++) {
-        const double *v = &hs->vertices[9 * i];
-        if (!have_normals) {
+        for (uint64_t i = chunk * per; i < std::min<uint64_t>(n, (chunk + 1) * per); i++) {
+            const double *v = &hs->vertices[9 * i];
             double ax = v[3] - v[0], ay = v[4] - v[1], az = v[5] - v[2];      // e01
             double bx = v[6] - v[0], by = v[7] - v[1], bz = v[8] - v[2];      // e02
             double cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
@@ -348,10 +377,25 @@ void setup_triangles(HostScene *hs, bool have_normals) {
             hs->normals[3 * i + 1] = cy / len;
             hs->normals[3 * i + 2] = cz / len;
         }
-        for (int k = 0; k < 3; k++) hs->centroids[3 * i + k] = ((v[k] + v[3 + k]) + v[6 + k]) / 3;
-    }
     });
 }
+
+namespace {
+
+// centroid = (v0 + v1 + v2) / 3, include/triangle.hpp:24
+void fill_centroids(HostScene *hs) {
+    const uint64_t n = hs->n_triangles();
+    hs->centroids.resize(3 * n);
+    const uint64_t per = 1u << 15;
+    parallel_for((n + per - 1) / per, [&](size_t chunk) {
+        for (uint64_t i = chunk * per; i < std::min<uint64_t>(n, (chunk + 1) * per); i++) {
+            const double *v = &hs->vertices[9 * i];
+            for (int k = 0; k < 3; k++) hs->centroids[3 * i + k] = ((v[k] + v[3 + k]) + v[6 + k]) / 3;
+        }
+    });
+}
+
+}  // namespace
 
 // The five factories, include/scene.hpp:255-448: they differ only in the file name
 // and the camera position.
@@ -383,9 +427,17 @@ int apply_preset(HostScene *hs, const std::string &preset, std::string *err) {
     hs->point_lights.clear();
     hs->directional_lights.assign(1, rtx_light{0.5, {0, 1, -1}});
     // parseOBJ materials (scene.hpp:240-242), then the overrides (scene.hpp:273-289)
-    hs->colors.assign(3 * n, 255);
-    hs->specularity.assign(n, 1);
-    hs->reflectivity.assign(n, 0.2);
+    hs->colors.resize(3 * n);
+    hs->specularity.resize(n);
+    hs->reflectivity.resize(n);
+    const uint64_t per = 1u << 16;
+    parallel_for((n + per - 1) / per, [&](size_t chunk) {
+        for (uint64_t i = chunk * per; i < std::min<uint64_t>(n, (chunk + 1) * per); i++) {
+            hs->colors[3 * i] = hs->colors[3 * i + 1] = hs->colors[3 * i + 2] = 255;
+            hs->specularity[i] = 1;
+            hs->reflectivity[i] = 0.2;
+        }
+    });
     for (uint64_t i = n - 10; i < n; i++) hs->reflectivity[i] = 0.4;
     for (uint64_t i = n - 4; i < n - 2; i++) { hs->colors[3 * i] = 0; hs->colors[3 * i + 2] = 0; }      // green
     for (uint64_t i = n - 2; i < n; i++) { hs->colors[3 * i + 1] = 0; hs->colors[3 * i + 2] = 0; }      // red
@@ -552,6 +604,7 @@ struct Builder {
 }  // namespace
 
 int build_bvh(HostScene *hs, std::string *err) {
+    fill_centroids(hs);         // Triangle ctor work, outside the reference's "[ BVH ]" time as well
     auto t0 = std::chrono::high_resolution_clock::now();
     Builder b(*hs);
     int rc = b.run(err);

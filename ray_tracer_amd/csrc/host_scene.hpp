@@ -7,21 +7,37 @@
 #define RTX_HOST_SCENE_HPP
 
 #include <cstdint>
+#include <memory>
+#include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "rtx.h"
 
 namespace rtx {
 
+// Allocator whose resize() leaves new elements unwritten: the big per-triangle arrays are filled
+// right after by worker threads, which then also take the first-touch page faults in parallel.
+template <typename T>
+struct DefaultInit : std::allocator<T> {
+    template <typename U> struct rebind { using other = DefaultInit<U>; };
+    DefaultInit() = default;
+    template <typename U> DefaultInit(const DefaultInit<U> &) {}
+    template <typename U> void construct(U *p) { ::new (static_cast<void *>(p)) U; }
+    template <typename U, typename... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
+using Doubles = std::vector<double, DefaultInit<double>>;
+using Ints = std::vector<int32_t, DefaultInit<int32_t>>;
+
 struct HostScene {
     // per triangle, index = the reference's index into Scene::triangles
-    std::vector<double> vertices;    // 9 per triangle
-    std::vector<double> normals;     // 3
-    std::vector<double> centroids;   // 3
-    std::vector<int32_t> colors;     // 3
-    std::vector<int32_t> specularity;
-    std::vector<double> reflectivity;
+    Doubles vertices;       // 9 per triangle
+    Doubles normals;        // 3
+    Doubles centroids;      // 3; filled by build_bvh when it needs them
+    Ints colors;            // 3
+    Ints specularity;
+    Doubles reflectivity;
     // BVH
     std::vector<rtx_bvh_node> nodes; // nodesUsed entries
     std::vector<uint64_t> indices;
@@ -39,9 +55,9 @@ struct HostScene {
 };
 
 // Each returns an rtx_status and leaves the message in `err`.
-int parse_obj(const std::string &path, std::vector<double> *vertices9, std::string *err);
+int parse_obj(const std::string &path, Doubles *vertices9, std::string *err);
 // General OBJ text: what tools/denormalize.py followed by Scene::parseOBJ accepts, each face once.
-int parse_obj_tolerant(const std::string &path, std::vector<double> *vertices9, std::string *err);
+int parse_obj_tolerant(const std::string &path, Doubles *vertices9, std::string *err);
 int apply_preset(HostScene *hs, const std::string &preset, std::string *err);
 // Triangle ctor work (include/triangle.hpp:21-24) for triangles lacking it.
 void setup_triangles(HostScene *hs, bool have_normals);

@@ -224,6 +224,20 @@ def test_number_literals_read_like_strtod(tmp_path):
         assert got.tobytes() == want.tobytes()        # bit for bit, signed zeros included
 
 
+def test_file_sizes_around_a_page_boundary_load_alike(tmp_path):
+    """The loaders map the file when its last page has room for a terminator and read it otherwise."""
+    body = "v 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\n" + "\n".join("f 1 2 3" for _ in range(9)) + "\nf 2 3 4"
+    want = None
+    for size in (4095, 4096, 4097, 8192):
+        path = tmp_path / f"padded_{size}.obj"
+        path.write_text("#" * (size - len(body) - 1) + "\n" + body)
+        assert os.path.getsize(path) == size
+        for tolerant in (False, True):
+            got = rt.HostScene.load_obj(str(path), "teapot", tolerant=tolerant, no_bvh=True).arrays()["vertices"]
+            want = got if want is None else want
+            assert got.shape == (10, 9) and got.tobytes() == want.tobytes()
+
+
 @pytest.mark.parametrize("w,h", [(1, 1), (7, 5), (300, 217), (1920, 37)])
 def test_png_writer_round_trips(tmp_path, w, h):
     """Decoded with zlib and struct only: signature, IHDR, one IDAT of stored blocks, IEND, every CRC."""
