@@ -134,6 +134,18 @@ int main(int argc, char **argv) {
         return -1;
     }
 
+    // REF_CAMERA="px,py,pz,rx,ry,rz" replaces the factory's camera (public members of Scene,
+    // include/scene.hpp:17-18): fixtures with a turned camera, which the stock factories never set.
+    if (const char *cam = getenv("REF_CAMERA")) {
+        double v[6];
+        if (sscanf(cam, "%lf,%lf,%lf,%lf,%lf,%lf", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]) != 6) {
+            fprintf(stderr, "ref_harness: REF_CAMERA needs six numbers\n");
+            return 2;
+        }
+        scene.cameraPosition = {v[0], v[1], v[2]};
+        scene.cameraRotation = {v[3], v[4], v[5]};
+    }
+
     size_t npx = static_cast<size_t>(out.W) * static_cast<size_t>(out.H);
     out.hit.assign(npx, -2);
     out.rgb.assign(npx * 3, 0);

@@ -50,19 +50,25 @@ inline V3 vmax(V3 a, V3 b) { return {a.x > b.x ? a.x : b.x, a.y > b.y ? a.y : b.
 inline double smin(double a, double b) { return (b < a) ? b : a; }
 inline double smax(double a, double b) { return (a < b) ? b : a; }
 
-// include/util.hpp:12-14 and include/vector3.hpp:54-82
+// include/util.hpp:12-14 and include/vector3.hpp:54-82.  Each rotate function of the reference
+// evaluates cos(radians) and sin(radians) of one argument; g++ -O3 (the reference's Makefile:7)
+// turns the pair into one sincos() call, whose sine is not always sin()'s to the last bit, so the
+// call is spelled out here instead of left to the optimiser.
 inline double to_radians(double deg) { return (deg / 180.0) * M_PI; }
 inline V3 rot_x(V3 v, double deg) {
-    double r = to_radians(deg);
-    return {v.x, std::cos(r) * v.y - std::sin(r) * v.z, std::sin(r) * v.y + std::cos(r) * v.z};
+    double s, c;
+    sincos(to_radians(deg), &s, &c);
+    return {v.x, c * v.y - s * v.z, s * v.y + c * v.z};
 }
 inline V3 rot_y(V3 v, double deg) {
-    double r = to_radians(deg);
-    return {std::cos(r) * v.x + std::sin(r) * v.z, v.y, -std::sin(r) * v.x + std::cos(r) * v.z};
+    double s, c;
+    sincos(to_radians(deg), &s, &c);
+    return {c * v.x + s * v.z, v.y, -s * v.x + c * v.z};
 }
 inline V3 rot_z(V3 v, double deg) {
-    double r = to_radians(deg);
-    return {std::cos(r) * v.x - std::sin(r) * v.y, std::sin(r) * v.x + std::cos(r) * v.y, v.z};
+    double s, c;
+    sincos(to_radians(deg), &s, &c);
+    return {c * v.x - s * v.y, s * v.x + c * v.y, v.z};
 }
 
 // include/triangle.hpp:8-25

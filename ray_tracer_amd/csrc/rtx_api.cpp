@@ -178,12 +178,15 @@ int finish_device_scene(rtx_scene *sc, const SceneCommon &c, uint64_t n, uint64_
     for (int k = 0; k < 3; k++) fast_ok = fast_ok && tame(c.camera_position[k]);
     d.fast_div_ok = fast_ok ? 1 : 0;
     // Vector3::rotateX/Y/Z call cos(radians) and sin(radians) with
-    // radians = (degrees / 180.0) * M_PI (util.hpp:12-14); same libm, same bits
+    // radians = (degrees / 180.0) * M_PI (util.hpp:12-14).  Built the reference's way (g++ -O3,
+    // Makefile:7) each of those functions makes ONE sincos() call for the pair, and glibc's sincos
+    // does not always return sin()'s last bit (-29.266614452137418 degrees: ...3194 against
+    // ...3199), so sincos it is: same libm entry point, same bits.
     const double rx = (c.camera_rotation_deg[0] / 180.0) * M_PI, ry = (c.camera_rotation_deg[1] / 180.0) * M_PI,
                  rz = (c.camera_rotation_deg[2] / 180.0) * M_PI;
-    d.cx = std::cos(rx); d.sx = std::sin(rx);
-    d.cy = std::cos(ry); d.sy = std::sin(ry);
-    d.cz = std::cos(rz); d.sz = std::sin(rz);
+    sincos(rx, &d.sx, &d.cx);
+    sincos(ry, &d.sy, &d.cy);
+    sincos(rz, &d.sz, &d.cz);
     d.ambient = c.ambient;
     d.bvh_depth = bvh_depth;
     return RTX_OK;

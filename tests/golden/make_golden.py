@@ -10,6 +10,10 @@ reference's own headers compiled from /root/reference, see oracle/ref_harness.cp
   tests/golden/teapot_128.npz        raw primary hit ids, unclamped RGB, primary t (128x128)
   tests/golden/bunny20010_192x108.npz  same for a stand-in mesh (the reference parses the
                                        .obj this repository's generator wrote)
+  tests/golden/teapot_turned_96x64.npz raw arrays for the teapot seen from TURNED_CAMERAS (the stock
+                                       factories only ever turn the camera by 0.1 degrees)
+
+`make_golden.py --turned-only` regenerates just the turned-camera fixtures and keeps the rest of golden.json.
 """
 import hashlib
 import json
@@ -29,9 +33,21 @@ REF_BRUTE = os.path.join(ROOT, "oracle", "_ref", "ref_brute")
 REFERENCE = "/root/reference"
 
 
-def run_ref(binary, scene, scene_root, W, H, depth, prefix="-", threads=8):
+# position, rotation in degrees: all three angles at once, a quarter turn, nearly half a turn
+TURNED_CAMERAS = [
+    ((3.5, 6.0, -9.0), (-29.266614452137418, -28.274912085355048, -4.294279981910943)),
+    ((-6.0, 5.0, -8.0), (20.0, 33.3, 7.0)),
+    ((0.0, 12.0, 0.5), (90.0, 0.0, 0.0)),
+    ((2.0, 3.0, 8.0), (10.0, 170.0, -15.0)),
+]
+
+
+def run_ref(binary, scene, scene_root, W, H, depth, prefix="-", threads=8, camera=None):
+    env = dict(os.environ)
+    if camera is not None:
+        env["REF_CAMERA"] = ",".join(repr(float(x)) for x in (*camera[0], *camera[1]))
     out = subprocess.run([binary, scene, scene_root, str(W), str(H), str(depth), prefix, str(threads)],
-                         check=True, capture_output=True, text=True).stdout
+                         check=True, capture_output=True, text=True, env=env).stdout
     d = {}
     for line in out.splitlines():
         if line.startswith("["):
@@ -50,10 +66,31 @@ def raw(prefix, W, H):
     )
 
 
+def turned(g, tmp):
+    arrays = {}
+    for k, cam in enumerate(TURNED_CAMERAS):
+        p = os.path.join(tmp, f"turned{k}")
+        g[f"teapot_turned{k}_96x64"] = run_ref(REF_BVH, "teapot", REFERENCE, 96, 64, 3, p, camera=cam)
+        g[f"teapot_turned{k}_96x64"]["camera"] = [list(cam[0]), list(cam[1])]
+        for name, a in raw(p, 96, 64).items():
+            arrays[f"{name}{k}"] = a
+        g[f"teapot_turned{k}_640x360"] = run_ref(REF_BVH, "teapot", REFERENCE, 640, 360, 3, camera=cam)
+    np.savez_compressed(os.path.join(HERE, "teapot_turned_96x64.npz"), **arrays)
+
+
 def main():
     import ray_tracer_amd as rt
 
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    if "--turned-only" in sys.argv:
+        path = os.path.join(HERE, "golden.json")
+        g = json.load(open(path))
+        with tempfile.TemporaryDirectory() as tmp:
+            turned(g, tmp)
+        with open(path, "w") as f:
+            json.dump(g, f, indent=1, sort_keys=True)
+        print("updated", path)
+        return
     shutil.copyfile(os.path.join(REFERENCE, "scenes", "teapot.obj"), os.path.join(HERE, "teapot.obj"))
     g = {"_generator": "tests/golden/make_golden.py", "_source": "oracle/_ref (reference headers compiled with g++ -O3)"}
     with tempfile.TemporaryDirectory() as tmp:
@@ -75,6 +112,7 @@ def main():
         with open(os.path.join(tmp, "nl", "scenes", "teapot.obj"), "wb") as f:
             f.write(open(os.path.join(REFERENCE, "scenes", "teapot.obj"), "rb").read() + b"\n")
         g["teapot_trailing_newline_64"] = run_ref(REF_BVH, "teapot", os.path.join(tmp, "nl"), 64, 64, 3)
+        turned(g, tmp)
         # ---- stand-in meshes: this repository's generator writes the .obj, the reference renders it
         cases = [("bunny", 20010, 7, 192, 108, True), ("bunny", 144056, 0, 480, 270, False),
                  ("erato", 412508, 0, 480, 270, False), ("dragon", 871316, 0, 960, 540, False),

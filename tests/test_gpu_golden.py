@@ -86,3 +86,22 @@ def test_full_size_modes_agree_and_census_is_canonical():
                         layout=rt.LAYOUT_PACKED_TILES).rgb for r in range(4)]
     assert np.array_equal(untile_reference(np.stack(parts), W, H, 32, 32, 4), a.rgb)
     dev.close()
+
+
+@pytest.mark.parametrize("k", [0, 1, 2, 3])
+def test_turned_cameras_match_reference_render(teapot_obj, golden, golden_dir, k):
+    """The teapot from cameras turned about all three axes (the stock scenes turn by 0.1 degrees only)."""
+    want = golden[f"teapot_turned{k}_96x64"]
+    position, rotation = want["camera"]
+    host = rt.HostScene.load_obj(teapot_obj, "teapot")
+    host.set_camera(position, rotation)
+    dev = rt.Scene(host)
+    raw = np.load(os.path.join(golden_dir, "teapot_turned_96x64.npz"))
+    for mode in (rt.TRAVERSAL_REFERENCE, rt.TRAVERSAL_PRUNED):
+        got = _render_all(dev, 96, 64, mode)
+        assert np.array_equal(got["hit"].reshape(64, 96), raw[f"hit{k}"])
+        assert np.array_equal(got["rgb_i32"].reshape(64, 96, 3), raw[f"rgb_i32{k}"])
+        assert got["t"].tobytes() == raw[f"t{k}"].tobytes()
+        _check(got, want)
+        _check(_render_all(dev, 640, 360, mode), golden[f"teapot_turned{k}_640x360"])
+    dev.close()

@@ -96,3 +96,22 @@ def test_standin_raw_arrays_from_reference(golden, golden_dir, tmp_path):
     got = s.render(192, 108, depth=3, want_t=True)
     assert np.array_equal(got["hit"], arr["hit"]) and np.array_equal(got["rgb_i32"], arr["rgb_i32"])
     assert got["t"].tobytes() == arr["t"].tobytes()
+
+
+@pytest.mark.parametrize("k", [0, 1, 2, 3])
+def test_turned_cameras(teapot, golden, golden_dir, k):
+    """All three rotation angles at once, quarter and half turns: pins cos/sin of the camera rotation the way
+    the reference's build evaluates them (vector3.hpp:54-82 under g++ -O3)."""
+    want = golden[f"teapot_turned{k}_96x64"]
+    position, rotation = want["camera"]
+    col, spec, refl = teapot.materials()
+    turned = OracleScene.from_arrays(teapot.geometry()[:, :9], col, spec, refl, camera_position=position,
+                                     camera_rotation_deg=rotation, ambient=0.2,
+                                     directional_lights=[(0.5, (0.0, 1.0, -1.0))])
+    raw = np.load(os.path.join(golden_dir, "teapot_turned_96x64.npz"))
+    got = turned.render(96, 64, depth=3, want_t=True)
+    assert np.array_equal(got["hit"], raw[f"hit{k}"])
+    assert np.array_equal(got["rgb_i32"], raw[f"rgb_i32{k}"])
+    assert got["t"].tobytes() == raw[f"t{k}"].tobytes()
+    _check_render(got, want)
+    _check_render(turned.render(640, 360, depth=3, want_t=True), golden[f"teapot_turned{k}_640x360"])
