@@ -146,6 +146,64 @@ int main(int argc, char **argv) {
         scene.cameraRotation = {v[3], v[4], v[5]};
     }
 
+    // REF_SCENE_FILE=<text file> overrides more of the factory's scene through Scene's public members
+    // (include/scene.hpp:15-23), one directive per line:
+    //   camera px py pz rx ry rz | viewport x y z | background r g b | ambient a | nolights |
+    //   point i x y z | directional i x y z | materials <file of {int32 r,g,b,spec; double refl} per triangle>
+    // Lights given here are appended after `nolights` cleared the factory's.  Materials only touch
+    // Scene::triangles, where traceRay reads them (scene.hpp:105-113); the BVH keeps its own copy of the geometry.
+    if (const char *path = getenv("REF_SCENE_FILE")) {
+        FILE *f = fopen(path, "r");
+        if (!f) { fprintf(stderr, "ref_harness: cannot read %s\n", path); return 2; }
+        char key[64];
+        while (fscanf(f, "%63s", key) == 1) {
+            std::string k = key;
+            double v[6];
+            bool ok = true;
+            if (k == "camera") {
+                ok = fscanf(f, "%lf %lf %lf %lf %lf %lf", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]) == 6;
+                scene.cameraPosition = {v[0], v[1], v[2]};
+                scene.cameraRotation = {v[3], v[4], v[5]};
+            } else if (k == "viewport") {
+                ok = fscanf(f, "%lf %lf %lf", &v[0], &v[1], &v[2]) == 3;
+                scene.viewport = {v[0], v[1], v[2]};
+            } else if (k == "background") {
+                int c[3];
+                ok = fscanf(f, "%d %d %d", &c[0], &c[1], &c[2]) == 3;
+                scene.backgroundColor = Color(c[0], c[1], c[2]);
+            } else if (k == "ambient") {
+                ok = fscanf(f, "%lf", &v[0]) == 1;
+                scene.ambientLight = v[0];
+            } else if (k == "nolights") {
+                scene.pointLights.clear();
+                scene.directionalLights.clear();
+            } else if (k == "point") {
+                ok = fscanf(f, "%lf %lf %lf %lf", &v[0], &v[1], &v[2], &v[3]) == 4;
+                scene.pointLights.push_back({v[0], {v[1], v[2], v[3]}});
+            } else if (k == "directional") {
+                ok = fscanf(f, "%lf %lf %lf %lf", &v[0], &v[1], &v[2], &v[3]) == 4;
+                scene.directionalLights.push_back({v[0], {v[1], v[2], v[3]}});
+            } else if (k == "materials") {
+                char mpath[4096];
+                ok = fscanf(f, "%4095s", mpath) == 1;
+                FILE *m = ok ? fopen(mpath, "rb") : nullptr;
+                ok = m != nullptr;
+                for (size_t i = 0; ok && i < scene.triangles.size(); i++) {
+                    struct { int32_t r, g, b, spec; double refl; } rec;
+                    ok = fread(&rec, sizeof rec, 1, m) == 1;
+                    scene.triangles[i].color = Color(rec.r, rec.g, rec.b);
+                    scene.triangles[i].specularity = rec.spec;
+                    scene.triangles[i].reflectivity = rec.refl;
+                }
+                if (m) fclose(m);
+            } else {
+                ok = false;
+            }
+            if (!ok) { fprintf(stderr, "ref_harness: bad directive '%s' in %s\n", key, path); return 2; }
+        }
+        fclose(f);
+    }
+
     size_t npx = static_cast<size_t>(out.W) * static_cast<size_t>(out.H);
     out.hit.assign(npx, -2);
     out.rgb.assign(npx * 3, 0);
