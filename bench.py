@@ -48,11 +48,25 @@ def cpu_baseline(scene_name, n_tris, W, H, depth, obj_path):
             cmd, kind = [cli, scene_name, obj_path, str(W), str(H), str(depth), "-", str(cores), "1", "1", "3"], "port"
         else:
             return None
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=900).stdout
-        secs = [float(l.split()[1]) for l in out.splitlines() if l.startswith("frame_seconds")]
+        def frames(command):
+            out = subprocess.run(command, capture_output=True, text=True, timeout=900).stdout
+            return [float(l.split()[1]) for l in out.splitlines() if l.startswith("frame_seconds")]
+
+        secs = frames(cmd)
         # the reference times three frames in a row (src/main.cpp:42-61); the median one counts here
-        return {"kind": kind, "cores": cores, "seconds": sorted(secs)[len(secs) // 2], "all": secs, "frames": len(secs),
-                "cmd": os.path.basename(cmd[0])}
+        res = {"kind": kind, "cores": cores, "seconds": sorted(secs)[len(secs) // 2], "all": secs, "frames": len(secs),
+               "cmd": os.path.basename(cmd[0])}
+        # the same program built for this host's vector units (-march=x86-64-v3, contraction off: same pixels)
+        v3 = ref + "_v3"
+        try:
+            flags = open("/proc/cpuinfo").read()
+            if kind == "reference" and os.path.exists(v3) and " avx2" in flags and " fma" in flags:
+                s3 = frames([v3] + cmd[1:])
+                if s3:
+                    res["v3_seconds"] = sorted(s3)[len(s3) // 2]
+        except Exception:
+            pass
+        return res
     except Exception as e:  # a missing baseline must not take the GPU number down with it
         return {"error": repr(e)}
 
@@ -322,6 +336,10 @@ def main():
                 "sample": f"same scene and camera at {cw}x{ch} ({srays} rays), median of {cb['frames']} frames "
                           f"({', '.join('%.3f' % x for x in cb['all'])} s) of {cb['cmd']} with {cb['cores']} threads",
             }
+            if "v3_seconds" in cb:
+                result["cpu_baseline"]["built_for_avx2_fma"] = {
+                    "value": round(srays / cb["v3_seconds"] / 1e6, 3), "unit": "Mrays/s",
+                    "flags": "-O3 -march=x86-64-v3 -ffp-contract=off (the reference's Makefile uses plain -O3)"}
         else:
             result["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port", "sample": repr(cb)}
     print(json.dumps(result))
