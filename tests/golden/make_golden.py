@@ -13,7 +13,8 @@ reference's own headers compiled from /root/reference, see oracle/ref_harness.cp
   tests/golden/teapot_turned_96x64.npz raw arrays for the teapot seen from TURNED_CAMERAS (the stock
                                        factories only ever turn the camera by 0.1 degrees)
 
-`make_golden.py --turned-only` regenerates just the turned-camera fixtures and keeps the rest of golden.json.
+`make_golden.py --turned-only` regenerates just the turned-camera fixtures and keeps the rest of golden.json;
+`--full-size-only` adds the hashes of the two benchmarked 3840x2160 frames as the reference renders them (minutes).
 """
 import hashlib
 import json
@@ -82,6 +83,25 @@ def main():
     import ray_tracer_amd as rt
 
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    if "--full-size-only" in sys.argv:
+        # the benchmarked frames themselves (BASELINE's dragon and aurelius at 3840x2160), rendered by the reference:
+        # minutes of CPU each, hashes only
+        path = os.path.join(HERE, "golden.json")
+        g = json.load(open(path))
+        with tempfile.TemporaryDirectory() as tmp:
+            for scene, ntri in (("dragon", 871316), ("aurelius", 1704768)):
+                root = os.path.join(tmp, scene)
+                os.makedirs(os.path.join(root, "scenes"))
+                obj = os.path.join(root, "scenes", f"{scene}.obj")
+                rt.HostScene.standin(scene, ntri, seed=0, obj_path_out=obj, no_bvh=True).close()
+                key = f"standin_{scene}_{ntri}_seed0_3840x2160"
+                g[key] = run_ref(REF_BVH, scene, root, 3840, 2160, 3)
+                g[key]["obj_md5"] = hashlib.md5(open(obj, "rb").read()).hexdigest()
+                shutil.rmtree(root)
+                print(key, g[key]["hit_fnv"], flush=True)
+                with open(path, "w") as f:
+                    json.dump(g, f, indent=1, sort_keys=True)
+        return
     if "--turned-only" in sys.argv:
         path = os.path.join(HERE, "golden.json")
         g = json.load(open(path))

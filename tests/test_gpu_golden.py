@@ -66,6 +66,22 @@ def test_standin_scenes_match_reference_render(scene, ntri, W, H, golden):
     dev.close()
 
 
+@pytest.mark.parametrize("scene,ntri", [("dragon", 871316), ("aurelius", 1704768)])
+def test_benchmarked_frames_equal_the_reference_render(scene, ntri, golden):
+    """BASELINE's two full-size frames (stand-in meshes, 3840x2160, depth 3) against the hashes of the reference's own
+    render of them: primary ids, t, unclamped and 8-bit RGB of all 8.3 M pixels, both traversal modes, tree built on
+    the device."""
+    key = f"standin_{scene}_{ntri}_seed0_3840x2160"
+    if key not in golden:
+        pytest.skip("full-size hashes not generated (tests/golden/make_golden.py --full-size-only)")
+    want = golden[key]
+    dev = rt.Scene(rt.HostScene.standin(scene, ntri, seed=0, no_bvh=True))
+    assert dev.bvh_nodes == int(want["nodes_used"])
+    for mode in (rt.TRAVERSAL_PRUNED, rt.TRAVERSAL_REFERENCE):
+        _check(_render_all(dev, 3840, 2160, mode), want)
+    dev.close()
+
+
 def test_full_size_modes_agree_and_census_is_canonical():
     """BASELINE's 4K dragon frame: too slow for the CPU oracle in a test, so it is checked through
     properties: both traversal modes give identical ids / RGB, every tile partition re-assembles to
