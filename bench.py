@@ -114,7 +114,13 @@ def main():
     dev = torch.device("cuda", ordinal)
     if world > 1:
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            # the gather's kernels compete with persistent render launches that fill every CU: a high-priority
+            # stream lets them take the first slots that come free
+            try:
+                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            except Exception:
+                opts = None
+            dist.init_process_group("nccl", device_id=dev, pg_options=opts)
         else:
             dist.init_process_group("gloo")
 

@@ -34,6 +34,10 @@ REF_BRUTE = os.path.join(ROOT, "oracle", "_ref", "ref_brute")
 REFERENCE = "/root/reference"
 
 
+# BASELINE's single-frame configurations at their full sizes
+FULL_SIZE = [("bunny", 144056, 1920, 1080), ("erato", 412508, 3840, 2160), ("dragon", 871316, 3840, 2160),
+             ("aurelius", 1704768, 3840, 2160)]
+
 # position, rotation in degrees: all three angles at once, a quarter turn, nearly half a turn
 TURNED_CAMERAS = [
     ((3.5, 6.0, -9.0), (-29.266614452137418, -28.274912085355048, -4.294279981910943)),
@@ -84,18 +88,20 @@ def main():
 
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
     if "--full-size-only" in sys.argv:
-        # the benchmarked frames themselves (BASELINE's dragon and aurelius at 3840x2160), rendered by the reference:
+        # BASELINE's frames themselves (bunny 1920x1080; erato, dragon, aurelius 3840x2160), rendered by the reference:
         # minutes of CPU each, hashes only
         path = os.path.join(HERE, "golden.json")
         g = json.load(open(path))
         with tempfile.TemporaryDirectory() as tmp:
-            for scene, ntri in (("dragon", 871316), ("aurelius", 1704768)):
+            for scene, ntri, W, H in FULL_SIZE:
+                if f"standin_{scene}_{ntri}_seed0_{W}x{H}" in g and "--force" not in sys.argv:
+                    continue
                 root = os.path.join(tmp, scene)
                 os.makedirs(os.path.join(root, "scenes"))
                 obj = os.path.join(root, "scenes", f"{scene}.obj")
                 rt.HostScene.standin(scene, ntri, seed=0, obj_path_out=obj, no_bvh=True).close()
-                key = f"standin_{scene}_{ntri}_seed0_3840x2160"
-                g[key] = run_ref(REF_BVH, scene, root, 3840, 2160, 3)
+                key = f"standin_{scene}_{ntri}_seed0_{W}x{H}"
+                g[key] = run_ref(REF_BVH, scene, root, W, H, 3)
                 g[key]["obj_md5"] = hashlib.md5(open(obj, "rb").read()).hexdigest()
                 shutil.rmtree(root)
                 print(key, g[key]["hit_fnv"], flush=True)

@@ -66,19 +66,20 @@ def test_standin_scenes_match_reference_render(scene, ntri, W, H, golden):
     dev.close()
 
 
-@pytest.mark.parametrize("scene,ntri", [("dragon", 871316), ("aurelius", 1704768)])
-def test_benchmarked_frames_equal_the_reference_render(scene, ntri, golden):
-    """BASELINE's two full-size frames (stand-in meshes, 3840x2160, depth 3) against the hashes of the reference's own
-    render of them: primary ids, t, unclamped and 8-bit RGB of all 8.3 M pixels, both traversal modes, tree built on
-    the device."""
-    key = f"standin_{scene}_{ntri}_seed0_3840x2160"
+@pytest.mark.parametrize("scene,ntri,W,H", [("bunny", 144056, 1920, 1080), ("erato", 412508, 3840, 2160),
+                                            ("dragon", 871316, 3840, 2160), ("aurelius", 1704768, 3840, 2160)])
+def test_benchmarked_frames_equal_the_reference_render(scene, ntri, W, H, golden):
+    """BASELINE's full-size single-sample frames (stand-in meshes, depth 3) against the hashes of the reference's own
+    render of them: primary ids, t, unclamped and 8-bit RGB of every pixel, both traversal modes, tree built on the
+    device."""
+    key = f"standin_{scene}_{ntri}_seed0_{W}x{H}"
     if key not in golden:
         pytest.skip("full-size hashes not generated (tests/golden/make_golden.py --full-size-only)")
     want = golden[key]
     dev = rt.Scene(rt.HostScene.standin(scene, ntri, seed=0, no_bvh=True))
     assert dev.bvh_nodes == int(want["nodes_used"])
     for mode in (rt.TRAVERSAL_PRUNED, rt.TRAVERSAL_REFERENCE):
-        _check(_render_all(dev, 3840, 2160, mode), want)
+        _check(_render_all(dev, W, H, mode), want)
     dev.close()
 
 

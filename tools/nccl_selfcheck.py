@@ -5,7 +5,8 @@ import torch, torch.distributed as dist, ctypes as C, zlib
 import ray_tracer_amd as rt
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev,
+                        pg_options=dist.ProcessGroupNCCL.Options(is_high_priority_stream=True))
 hs = rt.HostScene.load_obj("tests/golden/teapot.obj", "teapot", no_bvh=True)
 scene = rt.Scene(hs)
 W, H = 1920, 1080
