@@ -274,6 +274,12 @@ int rtx_selftest_division(uint64_t n, uint64_t seed, uint64_t *mismatches);
  * scenes use, does not go through pow here.)  No counterpart in the reference. */
 int rtx_selftest_pow(uint64_t n, uint64_t seed, uint64_t *differing, uint64_t *max_ulps);
 
+/* Device self-test of the square root (Vector3::magnitude, include/vector3.hpp:84-86, in the shading terms
+ * and in the Triangle constructor's normal, include/triangle.hpp:23): n seeded operands across the exponent
+ * range, against the host's correctly rounded sqrt.  *differing must come back 0: the path's bit-exactness
+ * rests on it (a GPU toolchain may offer a faster, less exact f64 sqrt).  No counterpart in the reference. */
+int rtx_selftest_sqrt(uint64_t n, uint64_t seed, uint64_t *differing);
+
 const char *rtx_last_error(void);
 const char *rtx_version(void);
 

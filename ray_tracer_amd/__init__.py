@@ -104,7 +104,7 @@ EXPORTS = (
     "rtx_scene_create", "rtx_scene_create_from_host", "rtx_scene_destroy", "rtx_scene_device_bytes",
     "rtx_render_params_default", "rtx_output_pixels", "rtx_render", "rtx_render_device", "rtx_render_device_timed",
     "rtx_untile",
-    "rtx_save_ppm", "rtx_save_png", "rtx_selftest_division", "rtx_selftest_pow", "rtx_last_error", "rtx_version",
+    "rtx_save_ppm", "rtx_save_png", "rtx_selftest_division", "rtx_selftest_pow", "rtx_selftest_sqrt", "rtx_last_error", "rtx_version",
     "rtx_host_scene_load_obj_ex", "rtx_host_scene_standin_ex",
     "rtx_bvh_build", "rtx_host_scene_rebuild_bvh", "rtx_scene_create_with_builder", "rtx_scene_build_seconds",
     "rtx_scene_bvh_nodes", "rtx_scene_bvh_depth",
@@ -169,6 +169,7 @@ def lib() -> C.CDLL:
     L.rtx_save_png.argtypes = [C.c_char_p, C.c_int32, C.c_int32, vp]
     L.rtx_selftest_division.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
     L.rtx_selftest_pow.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.rtx_selftest_sqrt.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
     L.rtx_bvh_build.argtypes = [C.POINTER(C.c_double), C.c_uint64, C.c_int32, C.c_int32, vp, C.POINTER(C.c_uint64),
                                 C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
     L.rtx_host_scene_rebuild_bvh.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
@@ -207,6 +208,13 @@ def selftest_pow(n: int = 1 << 20, seed: int = 1):
     d, m = C.c_uint64(), C.c_uint64()
     _check(lib().rtx_selftest_pow(n, seed, C.byref(d), C.byref(m)))
     return d.value, m.value
+
+
+def selftest_sqrt(n: int = 1 << 22, seed: int = 1) -> int:
+    """Results of the device's f64 sqrt that differ from the host's correctly rounded one (must be 0)."""
+    d = C.c_uint64()
+    _check(lib().rtx_selftest_sqrt(n, seed, C.byref(d)))
+    return d.value
 
 
 def make_params(width: int, height: int, *, depth: int = 3, spp: int = 1, seed: int = 0,

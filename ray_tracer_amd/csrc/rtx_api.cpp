@@ -883,6 +883,34 @@ static int selftest_pow_impl(uint64_t n, uint64_t seed, uint64_t *differing, uin
     return RTX_OK;
 }
 
+static int selftest_sqrt_impl(uint64_t n, uint64_t seed, uint64_t *differing) {
+    if (!differing) return fail(RTX_ERR_INVALID, "NULL argument");
+    *differing = 0;
+    if (n == 0) return RTX_OK;
+    std::vector<double> x(n), got(n);
+    uint64_t z = seed * 0x9E3779B97F4A7C15ull + 1;
+    auto next = [&]() { z ^= z << 13; z ^= z >> 7; z ^= z << 17; return z; };
+    for (uint64_t i = 0; i < n; i++) {
+        // a full 53-bit significand, exponents -500..500 for three quarters of the operands, -2..2 for the rest
+        const double m = 1.0 + (double)(next() >> 12) * 0x1p-52;
+        const int span = (i & 3) ? 1001 : 5;
+        x[i] = std::ldexp(m, (int)(next() % (uint64_t)span) - span / 2);
+    }
+    double *d_x = nullptr, *d_out = nullptr;
+    hipError_t err = hipMalloc((void **)&d_x, n * sizeof(double));
+    if (err == hipSuccess) err = hipMalloc((void **)&d_out, n * sizeof(double));
+    if (err == hipSuccess) err = hipMemcpy(d_x, x.data(), n * sizeof(double), hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = rtx::launch_sqrttest(d_x, d_out, n, nullptr);
+    if (err == hipSuccess) err = hipMemcpy(got.data(), d_out, n * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(d_x); (void)hipFree(d_out);
+    if (err != hipSuccess) return fail(RTX_ERR_DEVICE, std::string("sqrt self-test: ") + hipGetErrorString(err));
+    for (uint64_t i = 0; i < n; i++) {
+        const double want = std::sqrt(x[i]);
+        if (memcmp(&want, &got[i], 8) != 0) (*differing)++;
+    }
+    return RTX_OK;
+}
+
 int rtx_selftest_division(uint64_t n, uint64_t seed, uint64_t *mismatches) {
     if (!mismatches) return fail(RTX_ERR_INVALID, "NULL argument");
     unsigned long long *d = nullptr, h = 0;
@@ -1028,6 +1056,10 @@ int rtx_render(rtx_scene *sc, const rtx_render_params *p, uint8_t *rgb_out, int3
 
 int rtx_selftest_pow(uint64_t n, uint64_t seed, uint64_t *differing, uint64_t *max_ulps) {
     return guarded([&]() -> int { return selftest_pow_impl(n, seed, differing, max_ulps); });
+}
+
+int rtx_selftest_sqrt(uint64_t n, uint64_t seed, uint64_t *differing) {
+    return guarded([&]() -> int { return selftest_sqrt_impl(n, seed, differing); });
 }
 
 int rtx_save_png(const char *path, int32_t width, int32_t height, const uint8_t *rgb) {

@@ -31,6 +31,7 @@ int render_blocks_per_cu();
 hipError_t launch_render(const DevScene &sc, const DevRender &rp, bool prune, bool stats, uint32_t block_threads,
                          uint32_t grid_blocks, hipStream_t st);
 hipError_t launch_divtest(uint64_t seed, uint64_t n, unsigned long long *d_mismatches, hipStream_t st);
+hipError_t launch_sqrttest(const double *d_x, double *d_out, uint64_t n, hipStream_t st);
 hipError_t launch_powtest(const double *d_x, const int32_t *d_e, double *d_out, uint64_t n, hipStream_t st);
 hipError_t launch_untile(const uint8_t *src, uint8_t *dst, int W, int H, int tile_w, int tile_h, int tiles_x, int n_ranks,
                          uint64_t rank_stride, int bpp, hipStream_t st);

@@ -835,6 +835,19 @@ __global__ void __launch_bounds__(256) powtest_kernel(const double *x, const int
     if (i < n) out[i] = general_pow(x[i], (double)e[i]);
 }
 
+// Self-test of the square root as this library's kernels use it (mag(), the normal of a triangle):
+// out[i] = sqrt(x[i]).
+__global__ void __launch_bounds__(256) sqrttest_kernel(const double *x, double *out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = __builtin_sqrt(x[i]);
+}
+
+hipError_t launch_sqrttest(const double *d_x, double *d_out, uint64_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(sqrttest_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, d_x, d_out, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_powtest(const double *d_x, const int32_t *d_e, double *d_out, uint64_t n, hipStream_t st) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(powtest_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, d_x, d_e, d_out, n);

@@ -191,6 +191,12 @@ def test_device_pow_stays_within_two_ulps_of_the_hosts():
     assert max_ulps <= 2
 
 
+def test_device_sqrt_is_correctly_rounded():
+    # magnitudes in the shading terms and the triangle normals computed on the device rest on this
+    for seed in (1, 2):
+        assert rt.selftest_sqrt(1 << 23, seed) == 0
+
+
 def test_fast_division_is_bit_exact():
     # 2^28 operand pairs per seed, compared bitwise with the compiler's IEEE division on the device
     for seed in (1, 2):
