@@ -96,6 +96,12 @@ def main():
     ap.add_argument("--cpu-sample-div", type=int, default=1, help="CPU baseline renders (W/div) x (H/div)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started by hand without a launcher: become the launcher (a child process; nothing here has touched the GPU yet)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(29500 + os.getpid() % 2000), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     import numpy as np
     import torch
     import torch.distributed as dist
