@@ -7,6 +7,7 @@
 #include "rt_oracle.h"
 
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -351,10 +352,19 @@ double total_light(const ora_scene &s, V3 p, V3 n, V3 v, int spec, bool use_bvh,
 
 struct RGB { int r, g, b; };
 // include/color.hpp:47-53: each channel truncated toward zero separately
-inline RGB cmul(RGB c, double k) {
-    return {static_cast<int>(c.r * k), static_cast<int>(c.g * k), static_cast<int>(c.b * k)};
+// color.hpp:47-53 converts with static_cast<int>(double).  For a product that does not fit an int
+// (a very bright light) or is NaN the language leaves the result open; the reference as built for
+// x86-64 gets cvttsd2si's answer, INT_MIN, which the clamp of saveCanvas then turns into 0.  Spelled
+// out, so that the restatement does not depend on how a compiler treats the overflow.
+inline int to_int(double v) {
+    return (v < 2147483648.0 && v > -2147483649.0) ? static_cast<int>(v) : INT32_MIN;
 }
-inline RGB cadd(RGB a, RGB b) { return {a.r + b.r, a.g + b.g, a.b + b.b}; }
+inline RGB cmul(RGB c, double k) {
+    return {to_int(c.r * k), to_int(c.g * k), to_int(c.b * k)};
+}
+// int + int of color.hpp:31-37; sums past the int range wrap on x86-64
+inline int wrap_add(int a, int b) { return static_cast<int>(static_cast<uint32_t>(a) + static_cast<uint32_t>(b)); }
+inline RGB cadd(RGB a, RGB b) { return {wrap_add(a.r, b.r), wrap_add(a.g, b.g), wrap_add(a.b, b.b)}; }
 
 RGB trace(const ora_scene &s, V3 o, V3 r, double tmin, double tmax, int depth, bool use_bvh, Counters &c,
           Hit *first) {                                                  // scene.hpp:89-123

@@ -256,6 +256,13 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 
+// static_cast<int>(double) of color.hpp:47-53 the way the reference's x86-64 build does it
+// (cvttsd2si): a value that does not fit an int, or a NaN, becomes INT_MIN, where this GPU's
+// conversion would saturate (NaN -> 0).  Only very bright lights get there.
+__device__ __forceinline__ int to_int(double v) {
+    return (v < 2147483648.0 && v > -2147483649.0) ? (int)v : (int)0x80000000;
+}
+
 __device__ __forceinline__ int clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }   // color.hpp:23-29
 
 // ---------------------------------------------------------------------------------
@@ -566,7 +573,7 @@ __device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScen
         const int32_t pos = scr.i(0);
         const DevMat &mt = sc.mats[pos];
         const double total = scr.f(3);
-        const int lr = (int)(mt.color[0] * total), lg = (int)(mt.color[1] * total), lb = (int)(mt.color[2] * total);
+        const int lr = to_int(mt.color[0] * total), lg = to_int(mt.color[1] * total), lb = to_int(mt.color[2] * total);
         const double refl = mt.reflectivity;
         if (d == (uint32_t)rp.depth || refl < 0) {                      // scene.hpp:115-117
             cr = lr; cg = lg; cb = lb;
@@ -588,9 +595,10 @@ __device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScen
         const int lr = scr.i(1 + 3 * d), lg = scr.i(2 + 3 * d), lb = scr.i(3 + 3 * d);
         const double refl = scr.f(4 + d);
         const double keep = 1 - refl;
-        cr = (int)(lr * keep) + (int)(cr * refl);
-        cg = (int)(lg * keep) + (int)(cg * refl);
-        cb = (int)(lb * keep) + (int)(cb * refl);
+        // int + int wraps on both machines
+        cr = (int)((uint32_t)to_int(lr * keep) + (uint32_t)to_int(cr * refl));
+        cg = (int)((uint32_t)to_int(lg * keep) + (uint32_t)to_int(cg * refl));
+        cb = (int)((uint32_t)to_int(lb * keep) + (uint32_t)to_int(cb * refl));
     }
     // putPixel (src/main.cpp:90-94) + the clamp of saveCanvas (src/main.cpp:107)
     const uint64_t out = L.out;

@@ -151,6 +151,11 @@ def fuzz_case(seed, exotic_spec=False):
         directional_lights=[(float(rng.uniform(0.1, 0.8)), tuple(float(x) for x in rng.choice([0.0, 1.0, -1.0, 0.3], size=3)))
                             for _ in range(n_dir)],
     )
+    if rng.random() < 0.08:
+        # lights bright enough to push colour * lighting past the int range (color.hpp:47-53)
+        boost = float(rng.choice([1e8, 1e12, 1e300]))
+        kw["point_lights"] = [(i * boost, p) for i, p in kw["point_lights"]]
+        kw["directional_lights"] = [(i * boost, p) for i, p in kw["directional_lights"]]
     opts = dict(
         W=int(rng.choice([8, 33, 64, 96, 130])), H=int(rng.choice([8, 31, 64, 72])), depth=int(rng.integers(0, 6)),
         spp=int(rng.choice([1, 1, 1, 4])), seed=int(rng.integers(0, 1 << 30)),
