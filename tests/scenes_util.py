@@ -70,7 +70,8 @@ def fuzz_geometry(rng):
     family = int(rng.integers(0, 7))
     if family == 0:      # plain soup
         n = int(rng.integers(4, 3000))
-        scale = float(rng.choice([1e-3, 0.1, 1.0, 1.0, 30.0, 1e4]))
+        # the last three: products of coordinates go subnormal, or overflow
+        scale = float(rng.choice([1e-3, 0.1, 1.0, 1.0, 30.0, 1e4, 1.0, 1.0, 1e-3, 30.0, 1e-155, 1e-162, 1e140]))
         c = rng.uniform(-4, 4, size=(n, 1, 3)) * scale
         v = c + rng.uniform(-1.5, 1.5, size=(n, 3, 3)) * scale * float(rng.choice([0.05, 0.3, 1.0]))
         return "soup", v, scale
