@@ -238,6 +238,35 @@ def test_file_sizes_around_a_page_boundary_load_alike(tmp_path):
             assert got.shape == (10, 9) and got.tobytes() == want.tobytes()
 
 
+DENORMALIZE = "/root/reference/tools/denormalize.py"
+
+
+@pytest.mark.skipif(not os.path.exists(DENORMALIZE), reason="the reference's tools/ only exist in the build container")
+def test_tolerant_loader_equals_the_reference_script_followed_by_the_strict_loader(tmp_path):
+    """tools/denormalize.py itself (it reads scenes/bunny-o.obj and writes scenes/bunny.obj under the current directory)
+    on a mesh with vt/vn index groups and negative indices, then the strict loader on its output, against the tolerant
+    loader on the original.  The script's output ends in a newline, so the strict loader -- like the reference's -- reads
+    its last face twice; the tolerant loader reads every face once."""
+    import subprocess
+    import sys
+    rng = np.random.default_rng(11)
+    nv, nf = 50, 80
+    v = rng.normal(size=(nv, 3))
+    lines = ["# mesh", "o thing"] + ["v %r %r %r" % tuple(float(x) for x in p) for p in v] + ["vn 0 0 1", "vt 0.5 0.5"]
+    for k in range(nf):
+        a, b, c = (int(x) for x in rng.integers(1, nv + 1, size=3))
+        if k % 3 == 0: lines.append(f"f {a}/1 {b}/1 {c}/1")
+        elif k % 3 == 1: lines.append(f"f {a}//1 {b}//1 {c}//1")
+        else: lines.append(f"f {a - nv - 1}/1/1 {b - nv - 1}/1/1 {c - nv - 1}/1/1")
+    os.makedirs(tmp_path / "scenes")
+    (tmp_path / "scenes" / "bunny-o.obj").write_text("\n".join(lines) + "\n")
+    subprocess.run([sys.executable, DENORMALIZE], cwd=tmp_path, check=True)
+    strict = rt.HostScene.load_obj(str(tmp_path / "scenes" / "bunny.obj"), "teapot", no_bvh=True).arrays()["vertices"]
+    tolerant = rt.HostScene.load_obj(str(tmp_path / "scenes" / "bunny-o.obj"), "teapot", tolerant=True, no_bvh=True).arrays()["vertices"]
+    assert tolerant.shape == (nf, 9) and strict.shape == (nf + 1, 9)
+    assert strict[:nf].tobytes() == tolerant.tobytes() and strict[nf].tobytes() == strict[nf - 1].tobytes()
+
+
 @pytest.mark.parametrize("w,h", [(1, 1), (7, 5), (300, 217), (1920, 37)])
 def test_png_writer_round_trips(tmp_path, w, h):
     """Decoded with zlib and struct only: signature, IHDR, one IDAT of stored blocks, IEND, every CRC."""
