@@ -660,9 +660,11 @@ static int render_device_timed_impl(rtx_scene *sc, const rtx_render_params *p, v
     r.stack_stride = block;
     // Tuning knobs (environment overrides are for experiments).
     auto knob = [](const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; };
-    r.w_inner = knob("RTX_W_INNER", 1);
-    r.w_leaf = knob("RTX_W_LEAF", 2);
-    r.w_shade = knob("RTX_W_SHADE", 2);
+    // measured per traversal mode: the pruned walk has shorter runs of node steps
+    const bool pruned = p->traversal == RTX_TRAVERSAL_PRUNED;
+    r.w_inner = knob("RTX_W_INNER", pruned ? 3 : 1);
+    r.w_leaf = knob("RTX_W_LEAF", pruned ? 4 : 2);
+    r.w_shade = knob("RTX_W_SHADE", pruned ? 4 : 2);
     r.tail_lanes = knob("RTX_TAIL_LANES", 16);
     r.also_lanes = knob("RTX_ALSO_LANES", 24);
     r.also_leaf = knob("RTX_ALSO_LEAF", 16);

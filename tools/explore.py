@@ -36,7 +36,7 @@ exps = sys.argv[3:] or ["weights", "bpc", "queues", "tile"]
 if "weights" in exps:
     for wi, wl, ws in ((1, 1, 1), (1, 2, 2), (2, 3, 3), (1, 3, 3), (1, 2, 4), (1, 3, 2), (2, 3, 4), (3, 4, 4), (1, 4, 4), (1, 2, 3)):
         run(f"weights inner/leaf/shade={wi}/{wl}/{ws}", {"RTX_W_INNER": wi, "RTX_W_LEAF": wl, "RTX_W_SHADE": ws})
-    os.environ.update(RTX_W_INNER="1", RTX_W_LEAF="2", RTX_W_SHADE="2")
+    os.environ.update(RTX_W_INNER="3", RTX_W_LEAF="4", RTX_W_SHADE="4")
 if "bpc" in exps:
     for b in (2, 3, 4, 5, 6, 8):
         run(f"blocks per CU={b}", {"RTX_BLOCKS_PER_CU": b})
