@@ -45,3 +45,13 @@ if "weights2" in groups:
 if "tail" in groups:
     for t in (0, 8, 16, 32, 64):
         timed(f"tail_lanes={t}", RTX_TAIL_LANES=t)
+if "queues" in groups:
+    timed("single queue", RTX_XCD_QUEUES=0)
+    for m in (1, 2, 4, 8, 16, 32):
+        timed(f"8 XCD queues, macro={m} tiles", RTX_XCD_QUEUES=1, RTX_MACRO=m)
+    os.environ.update(RTX_XCD_QUEUES="1", RTX_MACRO="8")
+if "tile" in groups:
+    for t in (8, 16, 32, 64):
+        p = rt.make_params(W, H, traversal=rt.TRAVERSAL_PRUNED, tile=(t, t))
+        timed(f"tile={t}")
+    p = rt.make_params(W, H, traversal=rt.TRAVERSAL_PRUNED)
