@@ -225,6 +225,17 @@ def main():
         import zlib
         frame_crc = "%08x" % zlib.crc32(frames[(args.warmup + args.steps - 1) % F].cpu().numpy().tobytes())
 
+    # one frame at a time on one stream, each waited for: the latency of a frame (the headline above is throughput)
+    n1 = max(3, min(10, args.steps))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    for _ in range(n1):
+        renderer.submit()
+        renderer.synchronize()
+    alone_ms = (time.perf_counter() - t1) * 1e3 / n1
+
     # a second, short measurement of the other traversal mode (reported, never the headline)
     other_mode = rt.TRAVERSAL_REFERENCE if mode == rt.TRAVERSAL_PRUNED else rt.TRAVERSAL_PRUNED
     p2 = rt.make_params(W, H, depth=args.depth, spp=args.spp, traversal=other_mode, tile=(args.tile, args.tile),
@@ -278,6 +289,7 @@ def main():
             "bvh_build_kernels_ms": round(scene.build_seconds * 1e3, 3),
             "frame_crc32": frame_crc,
             "frames_in_flight": F,
+            "ms_per_frame_one_at_a_time": round(alone_ms, 4),
         },
         "roofline": {
             "bound": "hbm",
