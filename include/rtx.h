@@ -270,8 +270,9 @@ int rtx_selftest_division(uint64_t n, uint64_t seed, uint64_t *mismatches);
 /* Device self-test of the one libm call on the path whose bits are not pinned: pow(x, e) of
  * the specular term (include/scene.hpp:176) for n seeded cosines in (0, 1] and exponents
  * 2..1000, against the host's libm.  *differing: results that are not bit-equal; *max_ulps:
- * the largest distance in units of the last place.  (Exponent 1, the only one the shipped
- * scenes use, does not go through pow here.)  No counterpart in the reference. */
+ * the largest distance in units of the last place.  Powers below the normal range (they add
+ * nothing to a lighting sum) are left out.  (Exponent 1, the only one the shipped scenes
+ * use, does not go through pow here.)  No counterpart in the reference. */
 int rtx_selftest_pow(uint64_t n, uint64_t seed, uint64_t *differing, uint64_t *max_ulps);
 
 /* Device self-test of the square root (Vector3::magnitude, include/vector3.hpp:84-86, in the shading terms

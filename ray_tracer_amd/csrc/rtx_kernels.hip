@@ -220,9 +220,48 @@ struct Counters {
 };
 enum { C_PRIMARY, C_REFLECTION, C_SHADOW, C_OCCLUDED, C_CLOSEST, C_NODES, C_BOXHITS, C_LEAVES, C_TRIS };
 
-// Kept out of line: the inlined libm pow would raise the whole kernel's register count for a
-// term no shipped scene uses (specularity is 1 everywhere, scene.hpp:241).
-__device__ __attribute__((noinline)) double general_pow(double x, double e) { return pow(x, e); }
+// pow(x, specularity) of the specular term (scene.hpp:176): the exponent is an int, the base a cosine.
+// glibc's pow returns the correctly rounded power in all but a few cases per million; the device
+// libm's is within one unit of the last place, a different last bit in a fifth of the cases.  For
+// exponents 2 and up and an ordinary base the power is therefore computed here: square-and-multiply
+// on the base's significand in double-double arithmetic, binary exponents kept aside (error below
+// 2^-98 of the result after at most 60 products), rounded once -- the correctly rounded power unless
+// the exact value lies within 2^-98 of a rounding boundary.  Everything else -- other exponents, bases
+// that are not normal positive numbers, results outside the normal range -- goes to the device pow.
+// Kept out of line: inlined it would raise the whole kernel's register count for a term no shipped
+// scene uses (specularity is 1 everywhere, scene.hpp:241).
+struct DD { double hi, lo; };
+__device__ __forceinline__ DD dd_mul(DD a, DD b) {
+    const double p = a.hi * b.hi;
+    double e = __builtin_fma(a.hi, b.hi, -p);                      // exact error of p
+    e = __builtin_fma(a.hi, b.lo, __builtin_fma(a.lo, b.hi, e));   // a.lo * b.lo is below 2^-106 of the product
+    const double s = p + e;
+    return {s, e - (s - p)};                                        // |e| << |p|: the sum's error, exactly
+}
+// factors in [1, 2) give a product in [1, 4): back to [1, 2), exactly
+__device__ __forceinline__ void dd_halve_if_2(DD &v, long long &ex) {
+    if (v.hi >= 2.0) { v.hi *= 0.5; v.lo *= 0.5; ex++; }
+}
+__device__ __attribute__((noinline)) double general_pow(double x, double e) {
+    const int n = (int)e;
+    const uint32_t hi32 = (uint32_t)__double2hiint(x);
+    const uint32_t bexp = (hi32 >> 20) & 0x7ffu;                   // biased exponent (the sign bit must be 0)
+    const long long ex = (long long)bexp - 1023ll;
+    const bool ordinary = (double)n == e && n >= 2 && n <= 1 << 30 && x > 0.0 && bexp != 0u && bexp != 0x7ffu;
+    // x^n lies in [2^(ex n), 2^((ex + 1) n)): give up where that leaves the normal range
+    if (!ordinary || ex * n < -1021ll || (ex + 1) * n > 1023ll) return pow(x, e);
+    DD r = {1.0, 0.0};
+    DD b = {__hiloint2double((int)((hi32 & 0x000fffffu) | 0x3ff00000u), __double2loint(x)), 0.0};   // x / 2^ex, in [1, 2)
+    long long er = 0, eb = ex;
+    for (int k = n;;) {
+        if (k & 1) { r = dd_mul(r, b); er += eb; dd_halve_if_2(r, er); }
+        k >>= 1;
+        if (k == 0) break;
+        b = dd_mul(b, b); eb *= 2; dd_halve_if_2(b, eb);
+    }
+    if (er < -1022ll) return pow(x, e);                             // a subnormal result would be rounded twice
+    return ldexp(r.hi, (int)er);
+}
 
 __device__ __forceinline__ V3 reflect_ray(V3 ray, V3 n) {              // scene.hpp:185-187
     return sub(muls(smul(2.0, n), dot(n, ray)), ray);
@@ -548,8 +587,7 @@ __device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScen
                 const double rv = dot(R, v);
                 if (rv > 0) {
                     const double cosv = rv / (mag(R) * mag(v));
-                    // pow(x, 1) is x exactly in every libm; other exponents go through the
-                    // device pow, which may differ from glibc's in the last place
+                    // pow(x, 1) is x exactly in every libm; see general_pow for the other exponents
                     term += intensity * ((spec == 1) ? cosv : general_pow(cosv, (double)spec));
                 }
             }

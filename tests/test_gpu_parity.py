@@ -90,6 +90,7 @@ def test_soup_general_specular_exponent_within_one_lsb():
     assert np.array_equal(got.hit, want["hit"])
     diff = np.abs(got.rgb.astype(int) - want["rgb_u8"].astype(int))
     assert diff.max() <= 1
+    assert (diff != 0).mean() < 1e-4
     dev.close()
 
 
@@ -182,13 +183,15 @@ def test_errors_do_not_cross_as_exceptions_from_c(teapot):
         rt.HostScene.load_obj("/nonexistent/file.obj", "teapot")
 
 
-def test_device_pow_stays_within_two_ulps_of_the_hosts():
-    """The specular term's pow (scene.hpp:176) is the one libm call whose bits are not pinned; this bounds it.
-    A difference of a few ulps in the term moves a colour channel by at most one level, and only when
-    the product lands within 1e-13 of an integer."""
-    differing, max_ulps = rt.selftest_pow(1 << 22, seed=3)
-    print(f"device pow: {differing} of {1 << 22} results differ from glibc, at most {max_ulps} ulp")
-    assert max_ulps <= 2
+def test_device_pow_agrees_with_the_hosts():
+    """The specular term's pow (scene.hpp:176) is the one libm call whose bits are not pinned.  Integer exponents
+    from 2 up are computed in double-double on the device and rounded once; glibc's pow is correctly rounded except
+    for a few results in a thousand at the largest exponents, so nearly all results are bit-equal and none is
+    further than one unit of the last place."""
+    n = 1 << 22
+    differing, max_ulps = rt.selftest_pow(n, seed=3)
+    print(f"device pow: {differing} of {n} results differ from glibc, at most {max_ulps} ulp")
+    assert max_ulps <= 1 and differing <= n // 500
 
 
 def test_device_sqrt_is_correctly_rounded():
