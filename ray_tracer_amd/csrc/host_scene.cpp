@@ -170,6 +170,15 @@ void parallel_for(size_t n_items, F fn) {
 
 }  // namespace
 
+void parallel_copy(void *dst, const void *src, size_t bytes) {
+    const size_t piece = 1u << 20;
+    if (bytes < 4 * piece) { memcpy(dst, src, bytes); return; }
+    parallel_for((bytes + piece - 1) / piece, [&](size_t k) {
+        const size_t at = k * piece;
+        memcpy(static_cast<char *>(dst) + at, static_cast<const char *>(src) + at, std::min(piece, bytes - at));
+    });
+}
+
 // Scene::parseOBJ, include/scene.hpp:213-253.
 //
 // The reference tokenises with `fs >> id` (one non-blank char), then `fs >> x >> y >> z`

@@ -65,6 +65,9 @@ int build_bvh(HostScene *hs, std::string *err);
 int32_t measure_bvh_depth(const std::vector<rtx_bvh_node> &nodes);
 int validate_bvh(const HostScene &hs, std::string *err);
 
+// memcpy spread over the worker threads (a 4K frame is 25 MB: one thread takes longer than the GPU takes to render it).
+void parallel_copy(void *dst, const void *src, size_t bytes);
+
 // Stand-in mesh generator (scenegen.cpp): vertices9 of n_triangles faces,
 // the last 10 being the open box.
 int generate_standin(const std::string &preset, uint64_t n_triangles, uint64_t seed,

@@ -45,6 +45,10 @@ struct rtx_scene {
     void *d_order = nullptr;
     uint64_t order_capacity = 0;
     std::vector<int64_t> order_key;
+    // rtx_render()'s output buffers (device, and pinned host memory for the way back) and events, kept between calls
+    void *d_out_rgb = nullptr, *d_out_hit = nullptr, *d_out_stats = nullptr, *h_out_rgb = nullptr, *h_out_hit = nullptr;
+    uint64_t out_rgb_bytes = 0, out_hit_bytes = 0;
+    hipEvent_t out_e0 = nullptr, out_e1 = nullptr;
     uint64_t bytes = 0;
     uint64_t n_triangles = 0;
     double build_seconds = 0.0;   // BVH build inside rtx_scene_create*, 0 when the caller brought the tree
@@ -604,6 +608,13 @@ void rtx_scene_destroy(rtx_scene *sc) {
         if (sc->slot_done[k]) (void)hipEventDestroy(sc->slot_done[k]);
     }
     (void)hipFree(sc->d_order);
+    (void)hipFree(sc->d_out_rgb);
+    (void)hipFree(sc->d_out_hit);
+    (void)hipFree(sc->d_out_stats);
+    if (sc->h_out_rgb) (void)hipHostFree(sc->h_out_rgb);
+    if (sc->h_out_hit) (void)hipHostFree(sc->h_out_hit);
+    if (sc->out_e0) (void)hipEventDestroy(sc->out_e0);
+    if (sc->out_e1) (void)hipEventDestroy(sc->out_e1);
     delete sc;
 }
 
@@ -781,6 +792,18 @@ static int render_device_timed_impl(rtx_scene *sc, const rtx_render_params *p, v
     return RTX_OK;
 }
 
+// A device buffer and its pinned twin on the host, grown on demand and kept with the scene.
+static hipError_t grow_pair(void **dev, void **host, uint64_t *have, uint64_t need) {
+    if (need <= *have) return hipSuccess;
+    (void)hipFree(*dev);
+    if (*host) (void)hipHostFree(*host);
+    *dev = nullptr; *host = nullptr; *have = 0;
+    hipError_t e = hipMalloc(dev, need);
+    if (e == hipSuccess) e = hipHostMalloc(host, need, hipHostMallocDefault);
+    if (e == hipSuccess) *have = need;
+    return e;
+}
+
 static int render_impl(rtx_scene *sc, const rtx_render_params *p, uint8_t *rgb_out, int32_t *hit_id_out, rtx_stats *stats) {
     if (!sc) return fail(RTX_ERR_INVALID, "scene is NULL");
     if (!rgb_out) return fail(RTX_ERR_INVALID, "rgb_out is NULL");
@@ -792,46 +815,40 @@ static int render_impl(rtx_scene *sc, const rtx_render_params *p, uint8_t *rgb_o
     std::lock_guard<std::mutex> hold(sc->lock);
     DeviceGuard guard(sc->device);
     if (!guard.ok) return fail(RTX_ERR_DEVICE, "cannot select the scene's device");
-    void *d_rgb = nullptr, *d_hit = nullptr, *d_stats = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    int rc = RTX_OK;
-    auto cleanup = [&]() {
-        (void)hipFree(d_rgb); (void)hipFree(d_hit); (void)hipFree(d_stats);
-        if (e0) (void)hipEventDestroy(e0);
-        if (e1) (void)hipEventDestroy(e1);
-    };
-#define HIP_TRY_C(expr)                                                                                   \
-    do {                                                                                                  \
-        hipError_t e_ = (expr);                                                                           \
-        if (e_ != hipSuccess) { cleanup(); return fail(RTX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
-    } while (0)
-    HIP_TRY_C(hipMalloc(&d_rgb, px * 3));
-    HIP_TRY_C(hipMemset(d_rgb, 0, px * 3));
-    if (hit_id_out) { HIP_TRY_C(hipMalloc(&d_hit, px * 4)); HIP_TRY_C(hipMemset(d_hit, 0xff, px * 4)); }
-    if (stats) { HIP_TRY_C(hipMalloc(&d_stats, 15 * 8)); HIP_TRY_C(hipMemset(d_stats, 0, 15 * 8)); }
-    HIP_TRY_C(hipEventCreate(&e0));
-    HIP_TRY_C(hipEventCreate(&e1));
-    HIP_TRY_C(hipEventRecord(e0, nullptr));
-    rc = rtx_render_device(sc, p, d_rgb, d_hit, nullptr, nullptr, d_stats, nullptr);
-    if (rc != RTX_OK) { cleanup(); return rc; }
-    HIP_TRY_C(hipEventRecord(e1, nullptr));
-    HIP_TRY_C(hipEventSynchronize(e1));
-    HIP_TRY_C(hipMemcpy(rgb_out, d_rgb, px * 3, hipMemcpyDeviceToHost));
-    if (hit_id_out) HIP_TRY_C(hipMemcpy(hit_id_out, d_hit, px * 4, hipMemcpyDeviceToHost));
+    // Output lands in device buffers kept with the scene, travels to pinned host memory by DMA and is copied from
+    // there into the caller's (pageable) arrays on the worker threads: a pageable device-to-host copy of a 4K frame
+    // takes as long as rendering it.
+    HIP_TRY(grow_pair(&sc->d_out_rgb, &sc->h_out_rgb, &sc->out_rgb_bytes, px * 3));
+    if (hit_id_out) HIP_TRY(grow_pair(&sc->d_out_hit, &sc->h_out_hit, &sc->out_hit_bytes, px * 4));
+    if (stats && !sc->d_out_stats) HIP_TRY(hipMalloc(&sc->d_out_stats, 15 * 8));
+    if (!sc->out_e0) HIP_TRY(hipEventCreate(&sc->out_e0));
+    if (!sc->out_e1) HIP_TRY(hipEventCreate(&sc->out_e1));
+    void *d_rgb = sc->d_out_rgb, *d_hit = hit_id_out ? sc->d_out_hit : nullptr, *d_stats = stats ? sc->d_out_stats : nullptr;
+    hipStream_t stream = nullptr;
+    // pixels outside the window (and the padding of packed tiles) read 0 / -1
+    HIP_TRY(hipMemsetAsync(d_rgb, 0, px * 3, stream));
+    if (d_hit) HIP_TRY(hipMemsetAsync(d_hit, 0xff, px * 4, stream));
+    if (d_stats) HIP_TRY(hipMemsetAsync(d_stats, 0, 15 * 8, stream));
+    HIP_TRY(hipEventRecord(sc->out_e0, stream));
+    if (int rc = rtx_render_device(sc, p, d_rgb, d_hit, nullptr, nullptr, d_stats, stream)) return rc;
+    HIP_TRY(hipEventRecord(sc->out_e1, stream));
+    HIP_TRY(hipMemcpyAsync(sc->h_out_rgb, d_rgb, px * 3, hipMemcpyDeviceToHost, stream));
+    if (d_hit) HIP_TRY(hipMemcpyAsync(sc->h_out_hit, d_hit, px * 4, hipMemcpyDeviceToHost, stream));
+    unsigned long long c[15] = {};
+    if (d_stats) HIP_TRY(hipMemcpyAsync(c, d_stats, sizeof c, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    rtx::parallel_copy(rgb_out, sc->h_out_rgb, px * 3);
+    if (d_hit) rtx::parallel_copy(hit_id_out, sc->h_out_hit, px * 4);
     if (stats) {
-        unsigned long long c[15];
-        HIP_TRY_C(hipMemcpy(c, d_stats, sizeof c, hipMemcpyDeviceToHost));
         stats->primary_rays = c[0]; stats->reflection_rays = c[1]; stats->shadow_rays = c[2];
         stats->shadow_occluded = c[3]; stats->closest_hits = c[4]; stats->node_visits = c[5];
         stats->box_hits = c[6]; stats->leaf_visits = c[7]; stats->triangle_tests = c[8];
         for (int i = 0; i < 3; i++) { stats->rounds[i] = c[9 + i]; stats->lane_steps[i] = c[12 + i]; }
         float ms = 0;
-        HIP_TRY_C(hipEventElapsedTime(&ms, e0, e1));
+        HIP_TRY(hipEventElapsedTime(&ms, sc->out_e0, sc->out_e1));
         stats->kernel_ms = ms;
     }
-    cleanup();
     return RTX_OK;
-#undef HIP_TRY_C
 }
 
 int rtx_untile(const rtx_render_params *p, int32_t n_ranks, const void *d_gathered, void *d_out, int32_t bpp, void *stream) {
