@@ -122,3 +122,23 @@ def test_turned_cameras_match_reference_render(teapot_obj, golden, golden_dir, k
         _check(got, want)
         _check(_render_all(dev, 640, 360, mode), golden[f"teapot_turned{k}_640x360"])
     dev.close()
+
+
+def test_very_large_frame_modes_agree(teapot_obj):
+    """16384 x 8192 (134 M pixels, indices past 2^27 in every output array): both traversal modes give the same
+    ids and colours, and every pixel was written."""
+    import torch
+
+    dev = rt.Scene(rt.HostScene.load_obj(teapot_obj, "teapot", no_bvh=True))
+    W, H = 16384, 8192
+    out = []
+    for mode in (rt.TRAVERSAL_REFERENCE, rt.TRAVERSAL_PRUNED):
+        rgb = torch.full((H * W * 3,), 7, dtype=torch.uint8, device="cuda")
+        hit = torch.full((H * W,), -9, dtype=torch.int32, device="cuda")
+        dev.render_device(rt.make_params(W, H, traversal=mode), rgb_u8=rgb.data_ptr(), hit=hit.data_ptr())
+        torch.cuda.synchronize()
+        out.append((rgb, hit))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert int((out[0][1] == -9).sum()) == 0
+    assert int((out[0][1] >= 0).sum()) > W * H // 10        # the teapot and its box fill much of the frame
+    dev.close()
