@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <thread>
 
 #include "rtx.h"
@@ -80,6 +81,26 @@ int main(int argc, char **argv) {
     } catch (const char *e) {
         std::cerr << e;
         return -1;
+    }
+
+    // INTEGRATION.md's third route: the reference keeps its data structures and only the build moves to the GPU
+    {
+        std::vector<double> v;
+        for (Triangle &t : scene.triangles)
+            for (Vector3 q : {t.v0, t.v1, t.v2}) { v.push_back(q.x); v.push_back(q.y); v.push_back(q.z); }
+        const size_t n = scene.triangles.size();
+        std::vector<rtx_bvh_node> nodes(2 * n - 1);
+        std::vector<uint64_t> indices(n);
+        uint64_t used = 0;
+        if (rtx_bvh_build(v.data(), n, RTX_BUILDER_DEVICE, -1, nodes.data(), indices.data(), &used, nullptr, nullptr) != RTX_OK) {
+            std::cerr << rtx_last_error();
+            return -1;
+        }
+        const bool same = used == scene.bvh.nodesUsed && memcmp(nodes.data(), scene.bvh.nodes, used * sizeof(BVHNode)) == 0 &&
+                          memcmp(indices.data(), scene.bvh.indices.data(), n * sizeof(uint64_t)) == 0;
+        printf("rtx_bvh_build on the device: %llu nodes, %s BVH::nodes / BVH::indices\n", static_cast<unsigned long long>(used),
+               same ? "identical to" : "DIFFERENT from");
+        if (!same) return 1;
     }
 
     // per frame, instead of the 8 threads

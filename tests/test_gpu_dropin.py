@@ -22,3 +22,4 @@ def test_reference_main_with_the_binding_renders_the_reference_frame(teapot_obj,
     out = subprocess.run([DROPIN, str(tmp_path), "640", "400", mode, str(own_tree)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "pixels 256000 id_mismatches 0 rgb_mismatches 0" in out.stdout
+    assert "12541 nodes, identical to BVH::nodes / BVH::indices" in out.stdout
