@@ -102,6 +102,12 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(29500 + os.getpid() % 2000), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
 
+    # Libraries (gloo, RCCL, the HIP runtime) print notices on file descriptor 1; the one JSON line must be all that
+    # reaches standard output, so everything else is sent to standard error and the line is written to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -278,7 +284,7 @@ def main():
             "workload": f"{args.scene} ({host.n_triangles} triangles, {'real' if args.obj else 'stand-in'} mesh) "
                         f"{W}x{H}, depth {args.depth}, {args.spp} spp, traversal={args.mode}",
             "parallelism": f"screen tiles {args.tile}x{args.tile} interleaved over {world} GPU(s)"
-                           + (", RCCL all-gather of packed tiles" if packed else ""),
+                           + ((", RCCL all-gather of packed tiles" if args.backend == "nccl" else ", gloo all-gather through host memory (rehearsal)") if packed else ""),
             "rays_per_frame": rays,
             "rays_per_pixel": round(rays / (W * H), 3),
             "bvh_nodes": scene.bvh_nodes,
@@ -366,7 +372,8 @@ def main():
                     "flags": "-O3 -march=x86-64-v3 -ffp-contract=off (the reference's Makefile uses plain -O3)"}
         else:
             result["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port", "sample": repr(cb)}
-    print(json.dumps(result))
+    sys.stdout.flush()
+    os.write(real_stdout, (json.dumps(result) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 
