@@ -41,3 +41,25 @@ def test_host_only_calls_work_without_gpu():
     p.depth = 99
     assert lib.rtx_output_pixels(ctypes.byref(p)) == 0
     assert b"depth" in lib.rtx_last_error()
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """No CPU fallback stands behind the binding: without librtx.so every use raises."""
+    import subprocess
+    import sys
+    code = "import ray_tracer_amd as rt\ntry:\n    rt.lib()\nexcept rt.RtxError as e:\n    print('raised', e)\n"
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RTX_LIB=str(tmp_path / "absent.so"), PYTHONPATH=ROOT),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "raised" in out.stdout and "is missing" in out.stdout
+
+
+def test_render_without_a_gpu_is_an_error_not_a_fallback(teapot_obj):
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this machine has a GPU")
+    host = rt.HostScene.load_obj(teapot_obj, "teapot")          # loading and the host builder need no GPU
+    with pytest.raises(rt.RtxError):
+        rt.Scene(host)                                          # the device scene does
+    with pytest.raises(rt.RtxError):
+        rt.build_bvh(host.arrays()["vertices"], builder=rt.BUILDER_DEVICE)
