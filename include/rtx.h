@@ -11,6 +11,12 @@
  * the calling thread.  (The reference throws string literals that main() prints
  * and turns into exit code -1, src/main.cpp:27-32,65-70.)
  *
+ * Environment: results never depend on it.  For experiments the library reads, per launch,
+ * RTX_W_INNER / RTX_W_LEAF / RTX_W_SHADE / RTX_TAIL_LANES / RTX_ALSO_LANES / RTX_ALSO_LEAF /
+ * RTX_ALSO_SHADE (the wave scheduler's thresholds), RTX_BLOCKS_PER_CU, RTX_XCD_QUEUES, RTX_MACRO
+ * (work distribution) and RTX_WAVE_LOG=<file> (per-wave clock values; synchronous); the loaders
+ * print stage times to stderr under RTX_TIMING=1 and size their thread pool by OMP_NUM_THREADS.
+ *
  * Threading: a scene handle may be used from any thread.  rtx_render() serialises per
  * handle; rtx_render_device() launches may be in flight on several streams at once (up to
  * eight frames of one scene overlap, a ninth waits for the first).  All calls are
