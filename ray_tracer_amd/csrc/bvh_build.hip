@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <string>
@@ -1089,7 +1090,11 @@ int build_bvh_resident(const double *vertices, uint64_t n64, DeviceBvh *out, std
     DeviceBuffers &buf = out->impl->buf;
     // per triangle: 152 B of vertices and per-triangle records, ~40 B of index arrays, 2.1 node records of 92 B,
     // 136 B of output; per level node (n / 8 of them at most) 68 B of split data and 1248 B of bins
+    const auto t_reserve = std::chrono::steady_clock::now();
     HIP_TRY_B(buf.reserve((size_t)n * 700 + (16u << 20)));
+    if (getenv("RTX_TIMING"))
+        fprintf(stderr, "[rtx timing] %-22s %8.3f ms\n", "arena",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_reserve).count());
     double *V;
     TriRec *T;
     uint32_t *idx[2], *node_of[2], *local, *sums, *holes, *fills, *starts;
@@ -1123,7 +1128,12 @@ int build_bvh_resident(const double *vertices, uint64_t n64, DeviceBvh *out, std
     HIP_TRY_B(hipEventCreate(&ev0));
     HIP_TRY_B(hipEventCreate(&ev1));
     struct EventGuard { hipEvent_t a, b; ~EventGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } guard{ev0, ev1};
+    const bool timing = getenv("RTX_TIMING") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
     HIP_TRY_B(hipMemcpy(V, vertices, 9 * (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    if (timing)
+        fprintf(stderr, "[rtx timing] %-22s %8.3f ms\n", "vertices up",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     HIP_TRY_B(hipEventRecord(ev0, stream));
 
     const uint32_t pos_blocks = blocks_for(n);

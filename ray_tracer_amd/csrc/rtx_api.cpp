@@ -12,6 +12,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bvh_build.h"
@@ -84,6 +85,19 @@ int guarded(F &&body) {
         return fail(RTX_ERR_INVALID, "unexpected failure");
     }
 }
+
+// RTX_TIMING=1: stage times of scene creation on stderr.
+struct StageTimer {
+    const bool on = getenv("RTX_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what) {
+        if (!on) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[rtx timing] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
 
 // Selects a device for the current scope and puts the previous one back.
 struct DeviceGuard {
@@ -538,26 +552,43 @@ static int create_scene_built_on_device(const rtx_scene_desc *d, rtx_scene **out
 
     std::string err;
     rtx::DeviceBvh bvh;
-    if (int rc = rtx::build_bvh_resident(d->vertices, n, &bvh, &err)) return fail(rc, err);
-    const uint64_t m = bvh.n_nodes;
-    if (m + 1 >= (1ull << 28)) return fail(RTX_ERR_UNSUPPORTED, "more than 2^28 triangles or BVH nodes");
-
+    StageTimer timer;
     std::unique_ptr<rtx_scene, SceneDeleter> owner(new rtx_scene);
     rtx_scene *sc = owner.get();
     sc->device = device;
+    // The per-triangle arrays the flattening reads (normals if given, colours, exponents, reflectivities) go up on a
+    // helper thread and its own stream while this thread builds the tree: the copy engine is idle during the build.
     struct Temp { void *p = nullptr; ~Temp() { (void)hipFree(p); } } t_normals, t_colors, t_spec, t_refl;
-    auto stage = [&](Temp &t, const void *src, size_t bytes) -> hipError_t {
-        hipError_t e = hipMalloc(&t.p, bytes);
-        return e != hipSuccess ? e : hipMemcpy(t.p, src, bytes, hipMemcpyHostToDevice);
-    };
-    hipError_t e = hipMalloc(&sc->d_nodes, (m + 1) * sizeof(rtx::DevNode));
-    if (e == hipSuccess) e = hipMalloc(&sc->d_tris, n * sizeof(rtx::DevTri));
-    if (e == hipSuccess) e = hipMalloc(&sc->d_mats, n * sizeof(rtx::DevMat));
-    if (e == hipSuccess && d->normals) e = stage(t_normals, d->normals, 3 * n * sizeof(double));
-    if (e == hipSuccess) e = stage(t_colors, d->colors, 3 * n * sizeof(int32_t));
-    if (e == hipSuccess) e = stage(t_spec, d->specularity, n * sizeof(int32_t));
-    if (e == hipSuccess) e = stage(t_refl, d->reflectivity, n * sizeof(double));
+    hipError_t staged = hipSuccess;
+    std::thread uploader([&]() {
+        hipStream_t up = nullptr;
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
+        auto stage = [&](Temp &t, const void *src, size_t bytes) {
+            if (e == hipSuccess) e = hipMalloc(&t.p, bytes);
+            if (e == hipSuccess) e = hipMemcpyAsync(t.p, src, bytes, hipMemcpyHostToDevice, up);
+        };
+        if (e == hipSuccess) e = hipMalloc(&sc->d_tris, n * sizeof(rtx::DevTri));
+        if (e == hipSuccess) e = hipMalloc(&sc->d_mats, n * sizeof(rtx::DevMat));
+        if (d->normals) stage(t_normals, d->normals, 3 * n * sizeof(double));
+        stage(t_colors, d->colors, 3 * n * sizeof(int32_t));
+        stage(t_spec, d->specularity, n * sizeof(int32_t));
+        stage(t_refl, d->reflectivity, n * sizeof(double));
+        if (e == hipSuccess) e = hipStreamSynchronize(up);
+        if (up) (void)hipStreamDestroy(up);
+        staged = e;
+    });
+    struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join_on_exit{uploader};
+    const int build_rc = rtx::build_bvh_resident(d->vertices, n, &bvh, &err);
+    uploader.join();
+    if (build_rc != RTX_OK) return fail(build_rc, err);
+    timer.lap("upload + BVH build");
+    const uint64_t m = bvh.n_nodes;
+    if (m + 1 >= (1ull << 28)) return fail(RTX_ERR_UNSUPPORTED, "more than 2^28 triangles or BVH nodes");
+    hipError_t e = staged;
+    if (e == hipSuccess) e = hipMalloc(&sc->d_nodes, (m + 1) * sizeof(rtx::DevNode));
     if (e != hipSuccess) return fail(RTX_ERR_DEVICE, std::string("scene upload: ") + hipGetErrorString(e));
+    timer.lap("allocate, materials up");
     sc->bytes = (m + 1) * sizeof(rtx::DevNode) + n * (sizeof(rtx::DevTri) + sizeof(rtx::DevMat));
     int32_t boxes_tame = 0;
     double root_box[6];
@@ -565,6 +596,7 @@ static int create_scene_built_on_device(const rtx_scene_desc *d, rtx_scene **out
                                        (const double *)t_refl.p, (rtx::DevNode *)sc->d_nodes, (rtx::DevTri *)sc->d_tris,
                                        (rtx::DevMat *)sc->d_mats, &boxes_tame, root_box, &err);
     if (rc != RTX_OK) return fail(rc, err);
+    timer.lap("flatten");
     const SceneCommon common{d->viewport, d->camera_position, d->camera_rotation_deg, d->background, d->ambient,
                              d->point_lights, d->n_point_lights, d->directional_lights, d->n_directional_lights};
     rc = finish_device_scene(sc, common, n, m, root_box, boxes_tame != 0, bvh.depth);
