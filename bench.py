@@ -372,6 +372,9 @@ def main():
                     "flags": "-O3 -march=x86-64-v3 -ffp-contract=off (the reference's Makefile uses plain -O3)"}
         else:
             result["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port", "sample": repr(cb)}
+    if not args.obj and os.path.isdir(os.path.dirname(obj_dir)):
+        import shutil
+        shutil.rmtree(os.path.dirname(obj_dir), ignore_errors=True)          # the stand-in .obj written for the CPU baseline
     sys.stdout.flush()
     os.write(real_stdout, (json.dumps(result) + "\n").encode())
     if world > 1:
