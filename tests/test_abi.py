@@ -63,3 +63,15 @@ def test_render_without_a_gpu_is_an_error_not_a_fallback(teapot_obj):
         rt.Scene(host)                                          # the device scene does
     with pytest.raises(rt.RtxError):
         rt.build_bvh(host.arrays()["vertices"], builder=rt.BUILDER_DEVICE)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/rtx.h is what a C, cgo or FFI binding includes: it must compile as C99 on its own."""
+    import subprocess
+    src = tmp_path / "use_rtx.c"
+    src.write_text('#include "rtx.h"\nint main(void) { rtx_render_params p; rtx_render_params_default(&p, 4, 4); return p.depth != 3; }\n')
+    exe = tmp_path / "use_rtx"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", os.path.dirname(rt.LIB_PATH), "-lrtx", "-Wl,-rpath," + os.path.dirname(rt.LIB_PATH),
+                    "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"], check=True)
+    assert subprocess.run([str(exe)]).returncode == 0
