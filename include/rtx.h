@@ -97,7 +97,9 @@ typedef struct rtx_scene_desc {
 typedef struct rtx_host_scene rtx_host_scene;
 
 /* Replaces Scene::parseOBJ(path) + Scene::<preset>() (include/scene.hpp:213-448).
- * preset: "teapot", "bunny", "erato", "dragon" or "aurelius" -- camera position,
+ * preset: "teapot", "bunny", "erato", "dragon" or "aurelius" (or "showcase", no factory of the
+ * reference: the teapot's camera with two point lights, a directional light and specular
+ * exponents 10 and 50 on the model) -- camera position,
  * rotation (0, 0.1, 0) deg, white background, ambient 0.2, one directional light
  * 0.5 * (0,1,-1) and the last-10-triangles material overrides.  Prints the
  * reference's "[ TRI ] n triangles." / "[ BVH ] s seconds." lines when verbose. */

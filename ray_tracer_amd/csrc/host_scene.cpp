@@ -417,8 +417,12 @@ int apply_preset(HostScene *hs, const std::string &preset, std::string *err) {
         {"dragon", {-0.0425, 0.7115, -3.01725}},   // scene.hpp:376
         {"aurelius", {-0.025, 3.05, -20.9}},       // scene.hpp:415
     };
+    // "showcase": not one of the reference's factories.  The teapot's camera and materials, lit by what the shipped
+    // scenes never use: two point lights, a directional one, and specular exponents other than 1
+    // (scene.hpp:130-135,172-180).
+    const bool showcase = preset == "showcase";
     const P *p = nullptr;
-    for (const P &e : table) if (preset == e.name) p = &e;
+    for (const P &e : table) if (preset == e.name || (showcase && std::string(e.name) == "teapot")) p = &e;
     if (!p) { *err = "unknown scene preset '" + preset + "'"; return RTX_ERR_INVALID; }
     const uint64_t n = hs->vertices.size() / 9;
     if (n < 10) {
@@ -450,6 +454,16 @@ int apply_preset(HostScene *hs, const std::string &preset, std::string *err) {
     for (uint64_t i = n - 10; i < n; i++) hs->reflectivity[i] = 0.4;
     for (uint64_t i = n - 4; i < n - 2; i++) { hs->colors[3 * i] = 0; hs->colors[3 * i + 2] = 0; }      // green
     for (uint64_t i = n - 2; i < n; i++) { hs->colors[3 * i + 1] = 0; hs->colors[3 * i + 2] = 0; }      // red
+    if (showcase) {
+        hs->ambient = 0.15;
+        hs->point_lights = {rtx_light{0.6, {2.0, 6.0, -4.0}}, rtx_light{0.3, {-5.0, 3.0, -2.0}}};
+        hs->directional_lights.assign(1, rtx_light{0.3, {0, 1, -1}});
+        for (uint64_t i = 0; i + 10 < n; i++) {                   // the model: glossy, tinted; the box keeps exponent 1
+            hs->specularity[i] = (i % 3 == 0) ? 50 : 10;
+            hs->reflectivity[i] = 0.3;
+            hs->colors[3 * i] = 230; hs->colors[3 * i + 1] = 200; hs->colors[3 * i + 2] = 120;
+        }
+    }
     return RTX_OK;
 }
 

@@ -108,6 +108,36 @@ def main():
                 with open(path, "w") as f:
                     json.dump(g, f, indent=1, sort_keys=True)
         return
+    if "--showcase-only" in sys.argv:
+        # the library's "showcase" preset (point lights, specular exponents 10 and 50) rendered by the reference: its
+        # lights and materials go into the reference's Scene through the harness directives
+        path = os.path.join(HERE, "golden.json")
+        g = json.load(open(path))
+        hs = rt.HostScene.load_obj(os.path.join(HERE, "teapot.obj"), "showcase", no_bvh=True)
+        a, d = hs.arrays(), hs.desc()
+        with tempfile.TemporaryDirectory() as tmp:
+            rec = np.zeros(a["colors"].shape[0], dtype=np.dtype([("rgb", "<i4", 3), ("spec", "<i4"), ("refl", "<f8")]))
+            rec["rgb"], rec["spec"], rec["refl"] = a["colors"], a["specularity"], a["reflectivity"]
+            rec.tofile(os.path.join(tmp, "materials.bin"))
+            lines = ["ambient %r" % float(d.ambient), "nolights"]
+            lines += ["point %r %r %r %r" % (d.point_lights[i].intensity, *d.point_lights[i].v) for i in range(d.n_point_lights)]
+            lines += ["directional %r %r %r %r" % (d.directional_lights[i].intensity, *d.directional_lights[i].v)
+                      for i in range(d.n_directional_lights)]
+            lines += ["materials " + os.path.join(tmp, "materials.bin")]
+            open(os.path.join(tmp, "scene.txt"), "w").write("\n".join(lines) + "\n")
+            os.environ["REF_SCENE_FILE"] = os.path.join(tmp, "scene.txt")
+            p = os.path.join(tmp, "show")
+            g["teapot_showcase_160x120"] = run_ref(REF_BVH, "teapot", REFERENCE, 160, 120, 3, p)
+            np.savez_compressed(os.path.join(HERE, "teapot_showcase_160x120.npz"), **raw(p, 160, 120),
+                                rgb_u8=np.fromfile(p + ".rgb.u8", dtype=np.uint8).reshape(120, 160, 3))
+            g["teapot_showcase_1920x1080"] = run_ref(REF_BVH, "teapot", REFERENCE, 1920, 1080, 3, p)
+            np.savez_compressed(os.path.join(HERE, "teapot_showcase_1920x1080_rgb.npz"),
+                                rgb_u8=np.fromfile(p + ".rgb.u8", dtype=np.uint8).reshape(1080, 1920, 3))
+            del os.environ["REF_SCENE_FILE"]
+        with open(path, "w") as f:
+            json.dump(g, f, indent=1, sort_keys=True)
+        print("updated", path)
+        return
     if "--turned-only" in sys.argv:
         path = os.path.join(HERE, "golden.json")
         g = json.load(open(path))

@@ -142,3 +142,25 @@ def test_very_large_frame_modes_agree(teapot_obj):
     assert int((out[0][1] == -9).sum()) == 0
     assert int((out[0][1] >= 0).sum()) > W * H // 10        # the teapot and its box fill much of the frame
     dev.close()
+
+
+def test_showcase_scene_matches_reference_render(teapot_obj, golden, golden_dir):
+    """Point lights and specular exponents 10 / 50 (the "showcase" preset) against the reference's render of the same
+    lights and materials: ids and t bit for bit; colours may differ by one level where glibc's pow is not correctly
+    rounded (none does in these frames' 2.1 M pixels, but the bar stays the north star's)."""
+    dev = rt.Scene(rt.HostScene.load_obj(teapot_obj, "showcase", no_bvh=True))
+    raw = np.load(os.path.join(golden_dir, "teapot_showcase_160x120.npz"))
+    big = np.load(os.path.join(golden_dir, "teapot_showcase_1920x1080_rgb.npz"))["rgb_u8"]
+    for mode in (rt.TRAVERSAL_REFERENCE, rt.TRAVERSAL_PRUNED):
+        got = _render_all(dev, 160, 120, mode)
+        assert np.array_equal(got["hit"].reshape(120, 160), raw["hit"])
+        assert got["t"].tobytes() == raw["t"].tobytes()
+        diff = np.abs(got["rgb_u8"].reshape(120, 160, 3).astype(int) - raw["rgb_u8"].astype(int))
+        assert diff.max() <= 1 and (diff != 0).mean() < 1e-4
+        full = _render_all(dev, 1920, 1080, mode)
+        assert fnv1a(full["hit"]) == golden["teapot_showcase_1920x1080"]["hit_fnv"]
+        assert fnv1a(full["t"]) == golden["teapot_showcase_1920x1080"]["t_fnv"]
+        diff = np.abs(full["rgb_u8"].reshape(1080, 1920, 3).astype(int) - big.astype(int))
+        print("showcase 1920x1080: channel values differing from the reference's:", int((diff != 0).sum()))
+        assert diff.max() <= 1 and (diff != 0).mean() < 1e-4
+    dev.close()

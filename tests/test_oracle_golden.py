@@ -115,3 +115,22 @@ def test_turned_cameras(teapot, golden, golden_dir, k):
     assert got["t"].tobytes() == raw[f"t{k}"].tobytes()
     _check_render(got, want)
     _check_render(turned.render(640, 360, depth=3, want_t=True), golden[f"teapot_turned{k}_640x360"])
+
+
+def test_showcase_scene(teapot, golden, golden_dir):
+    """The library's "showcase" preset -- two point lights, a directional light, specular exponents 10 and 50 -- as the
+    reference renders it with those lights and materials set (same glibc pow on both sides: exact)."""
+    import ray_tracer_amd as rt
+    hs = rt.HostScene.load_obj(os.path.join(golden_dir, "teapot.obj"), "showcase", no_bvh=True)
+    a, d = hs.arrays(), hs.desc()
+    lights = lambda arr, n: [(arr[i].intensity, tuple(arr[i].v)) for i in range(n)]
+    ora = OracleScene.from_arrays(a["vertices"], a["colors"], a["specularity"], a["reflectivity"],
+                                  camera_position=tuple(a["camera_position"]), camera_rotation_deg=tuple(a["camera_rotation_deg"]),
+                                  ambient=d.ambient, point_lights=lights(d.point_lights, d.n_point_lights),
+                                  directional_lights=lights(d.directional_lights, d.n_directional_lights))
+    assert d.n_point_lights == 2 and set(np.unique(a["specularity"])) == {1, 10, 50}
+    raw = np.load(os.path.join(golden_dir, "teapot_showcase_160x120.npz"))
+    got = ora.render(160, 120, depth=3, want_t=True)
+    assert np.array_equal(got["hit"], raw["hit"]) and np.array_equal(got["rgb_i32"], raw["rgb_i32"])
+    assert got["t"].tobytes() == raw["t"].tobytes()
+    _check_render(got, golden["teapot_showcase_160x120"])
