@@ -83,10 +83,11 @@ def main():
     ap.add_argument("--spp", type=int, default=1)
     ap.add_argument("--mode", choices=["reference", "pruned"], default="pruned")
     ap.add_argument("--tile", type=int, default=32)
-    ap.add_argument("--inflight", type=int, default=4,
+    ap.add_argument("--inflight", type=int, default=None,
                     help="frames in flight: step i runs on stream i %% INFLIGHT, so the end of a frame (lanes running dry) "
                          "overlaps the start of the next one; 1 = every frame waits for the previous one; 4 = one stream "
-                         "per hardware queue of the process")
+                         "per hardware queue of the process (the default on one GPU); with several ranks the default is 8 and the "
+                         "process asks for 8 hardware queues: a rank's share of a frame is short, so more of them overlap")
     ap.add_argument("--obj", default=None, help="real .obj for the scene (default: the seeded stand-in mesh)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -101,6 +102,11 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(29500 + os.getpid() % 2000), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
+
+    if args.inflight is None:
+        args.inflight = 8 if int(os.environ.get("WORLD_SIZE", "1")) > 1 else 4
+    if args.inflight > 4:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")       # read by the HIP runtime when it starts; 4 is its default
 
     # Libraries (gloo, RCCL, the HIP runtime) print notices on file descriptor 1; the one JSON line must be all that
     # reaches standard output, so everything else is sent to standard error and the line is written to the saved descriptor.
