@@ -86,8 +86,8 @@ def main():
     ap.add_argument("--inflight", type=int, default=None,
                     help="frames in flight: step i runs on stream i %% INFLIGHT, so the end of a frame (lanes running dry) "
                          "overlaps the start of the next one; 1 = every frame waits for the previous one; 4 = one stream "
-                         "per hardware queue of the process (the default on one GPU); with several ranks the default is 8 and the "
-                         "process asks for 8 hardware queues: a rank's share of a frame is short, so more of them overlap")
+                         "per hardware queue of the process (the default); from 8 ranks up the default is 8 and the process asks for 8 "
+                         "hardware queues: a rank's share of a frame is short then, so more of them overlap")
     ap.add_argument("--obj", default=None, help="real .obj for the scene (default: the seeded stand-in mesh)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -104,7 +104,7 @@ def main():
         raise SystemExit(subprocess.call(cmd))
 
     if args.inflight is None:
-        args.inflight = 8 if int(os.environ.get("WORLD_SIZE", "1")) > 1 else 4
+        args.inflight = 8 if int(os.environ.get("WORLD_SIZE", "1")) >= 8 else 4       # measured: tools/shard_time.py
     if args.inflight > 4:
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")       # read by the HIP runtime when it starts; 4 is its default
 
