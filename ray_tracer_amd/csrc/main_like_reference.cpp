@@ -1,0 +1,33 @@
+// A driver with the shape of the reference's src/main.cpp:24-73, written against include/rtx_reference_api.hpp:
+// Scene::teapot(), render(scene, xMin, xMax) over eight column strips, three timed repeats printed in seconds with
+// three decimals, saveCanvas(), string literals thrown on failure and turned into exit code -1.  Run from a
+// directory that holds scenes/teapot.obj and out/, as the reference is.
+#define CANVAS_WIDTH 1920
+#define CANVAS_HEIGHT 1920
+#include "rtx_reference_api.hpp"
+
+#include <chrono>
+#include <iomanip>
+#include <iostream>
+
+int main(int argc, char **argv) {
+    const bool one_call = argc > 1 && std::string(argv[1]) == "--whole-frame";   // one render() for the whole width
+    Scene scene;
+    try {
+        scene = Scene::teapot();
+        const int strips = one_call ? 1 : 8, width = CANVAS_WIDTH / strips;
+        std::cout << std::fixed << std::setprecision(3);
+        for (int repeat = 0; repeat < 3; repeat++) {
+            const auto begin = std::chrono::high_resolution_clock::now();
+            for (int k = 0, x = -CANVAS_WIDTH / 2; k < strips; k++, x += width) render(scene, x, x + width);
+            const auto spent = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - begin);
+            std::cout << static_cast<double>(spent.count()) / 1000 << " ";
+        }
+        std::cout << "\n";
+        saveCanvas();
+    } catch (const char *message) {
+        std::cerr << message;
+        return -1;
+    }
+    return 0;
+}
