@@ -9,9 +9,11 @@
 #include <chrono>
 #include <iomanip>
 #include <iostream>
+#include <thread>
 
 int main(int argc, char **argv) {
     const bool one_call = argc > 1 && std::string(argv[1]) == "--whole-frame";   // one render() for the whole width
+    const bool threaded = argc > 1 && std::string(argv[1]) == "--threads";       // the strips from eight threads at once, as the reference starts them
     Scene scene;
     try {
         scene = Scene::teapot();
@@ -19,7 +21,19 @@ int main(int argc, char **argv) {
         std::cout << std::fixed << std::setprecision(3);
         for (int repeat = 0; repeat < 3; repeat++) {
             const auto begin = std::chrono::high_resolution_clock::now();
-            for (int k = 0, x = -CANVAS_WIDTH / 2; k < strips; k++, x += width) render(scene, x, x + width);
+            if (threaded) {
+                std::vector<std::thread> pool;
+                std::vector<const char *> failed(strips, nullptr);
+                for (int k = 0, x = -CANVAS_WIDTH / 2; k < strips; k++, x += width)
+                    pool.emplace_back([&failed, scene, k, x, width]() {
+                        try { render(scene, x, x + width); } catch (const char *message) { failed[k] = message; }
+                    });
+                for (std::thread &t : pool) t.join();
+                for (const char *message : failed)
+                    if (message) throw "a render thread failed\n";
+            } else {
+                for (int k = 0, x = -CANVAS_WIDTH / 2; k < strips; k++, x += width) render(scene, x, x + width);
+            }
             const auto spent = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - begin);
             std::cout << static_cast<double>(spent.count()) / 1000 << " ";
         }

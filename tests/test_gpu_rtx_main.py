@@ -45,7 +45,7 @@ def test_unwritable_output_ends_like_the_reference(teapot_obj, tmp_path):
 LIKE = os.path.join(ROOT, "ray_tracer_amd", "main_like_reference")
 
 
-@pytest.mark.parametrize("args", [[], ["--whole-frame"]])
+@pytest.mark.parametrize("args", [[], ["--whole-frame"], ["--threads"]])
 def test_driver_written_against_the_reference_shaped_header(teapot_obj, golden_dir, tmp_path, args):
     """main_like_reference.cpp uses include/rtx_reference_api.hpp -- Scene::teapot(), render(scene, xMin, xMax) over
     eight column strips (or one call for the whole width), saveCanvas() -- and must leave the reference's canvas.ppm."""
