@@ -238,7 +238,9 @@ uint64_t rtx_output_pixels(const rtx_render_params *p);
 /* One frame into HOST buffers.  Replaces the 8-thread render() fan-out and join
  * (src/main.cpp:45-52).  rgb_out: 3 bytes per pixel, clamped as saveCanvas does
  * (src/main.cpp:107); hit_id_out (nullable): primary-ray triangle id or -1;
- * stats (nullable): asks the kernel to count its work. */
+ * stats (nullable): asks the kernel to count its work.  The scene keeps the frame-sized
+ * device buffer and pinned host buffer this call stages through (grown on demand, released by
+ * rtx_scene_destroy). */
 int rtx_render(rtx_scene *scene, const rtx_render_params *p, uint8_t *rgb_out, int32_t *hit_id_out,
                rtx_stats *stats);
 
