@@ -89,6 +89,9 @@ def main():
                          "per hardware queue of the process (the default); from 8 ranks up the default is 8 and the process asks for 8 "
                          "hardware queues: a rank's share of a frame is short then, so more of them overlap")
     ap.add_argument("--obj", default=None, help="real .obj for the scene (default: the seeded stand-in mesh)")
+    ap.add_argument("--tolerant", action="store_true",
+                    help="read --obj with the general loader (vt/vn index groups, negative indices, comments) instead of the "
+                         "reference's grammar")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo stages the tile gather through host memory: a rehearsal of the N > 1 path on a box with fewer "
@@ -157,7 +160,7 @@ def main():
     obj_path = os.path.join(obj_dir, f"{args.scene}.obj")
     t0 = time.time()
     if args.obj:
-        host = rt.HostScene.load_obj(args.obj, args.scene, no_bvh=True)
+        host = rt.HostScene.load_obj(args.obj, args.scene, no_bvh=True, tolerant=args.tolerant)
         data = "real mesh"
         obj_path = args.obj
     else:
