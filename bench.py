@@ -41,6 +41,14 @@ def cpu_baseline(scene_name, n_tris, W, H, depth, obj_path):
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_bvh")
     cli = os.path.join(ROOT, "oracle", "oracle_cli")
     scene_root = os.path.dirname(os.path.dirname(obj_path))
+    linked = None
+    if os.path.basename(os.path.dirname(obj_path)) != "scenes" or os.path.basename(obj_path) != scene_name + ".obj":
+        # the reference's factories open scenes/<name>.obj under the current directory (scene.hpp:262): give them that view
+        import tempfile
+        linked = tempfile.mkdtemp(prefix="rtx_bench_scene_")
+        os.makedirs(os.path.join(linked, "scenes"))
+        os.symlink(os.path.abspath(obj_path), os.path.join(linked, "scenes", scene_name + ".obj"))
+        scene_root = linked
     try:
         if os.path.exists(ref):
             cmd, kind = [ref, scene_name, scene_root, str(W), str(H), str(depth), "-", str(cores), "3"], "reference"
@@ -69,6 +77,10 @@ def cpu_baseline(scene_name, n_tris, W, H, depth, obj_path):
         return res
     except Exception as e:  # a missing baseline must not take the GPU number down with it
         return {"error": repr(e)}
+    finally:
+        if linked:
+            import shutil
+            shutil.rmtree(linked, ignore_errors=True)
 
 
 def main():
