@@ -42,10 +42,8 @@ struct rtx_scene {
     hipEvent_t slot_done[kSlots] = {};
     uint32_t next_slot = 0;
     std::mutex slot_lock;
-    // work-queue layout of the last launch geometry (see build_tile_order)
-    void *d_order = nullptr;
-    uint64_t order_capacity = 0;
-    std::vector<int64_t> order_key;
+    // launch geometry whose work-queue table each slot's scratch holds (see tile_order_kernel)
+    std::vector<int64_t> slot_key[kSlots];
     // rtx_render()'s output buffers (device, and pinned host memory for the way back) and events, kept between calls
     void *d_out_rgb = nullptr, *d_out_hit = nullptr, *d_out_stats = nullptr, *h_out_rgb = nullptr, *h_out_hit = nullptr;
     uint64_t out_rgb_bytes = 0, out_hit_bytes = 0;
@@ -639,7 +637,6 @@ void rtx_scene_destroy(rtx_scene *sc) {
         (void)hipFree(sc->d_scratch[k]);
         if (sc->slot_done[k]) (void)hipEventDestroy(sc->slot_done[k]);
     }
-    (void)hipFree(sc->d_order);
     (void)hipFree(sc->d_out_rgb);
     (void)hipFree(sc->d_out_hit);
     (void)hipFree(sc->d_out_stats);
@@ -679,12 +676,23 @@ int rtx_render_device(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8,
     return rtx_render_device_timed(sc, p, d_rgb_u8, d_hit_id, d_rgb_i32, d_t, d_stats, nullptr, stream);
 }
 
-static int render_device_timed_impl(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id, void *d_rgb_i32, void *d_t,
-                            void *d_stats, void *d_ticks, void *stream) {
+// What a render launch needs besides its scratch memory: the resolved parameters with the output
+// pointers and scheduler settings in place, and the launch geometry.
+struct LaunchPlan {
+    rtx::DevRender r{};
+    uint32_t block = 256;        // threads per block (a power of two, 64..256)
+    uint64_t grid_blocks = 0;    // blocks of the persistent launch; 0 = nothing to render
+    int n_queues = 8, macro = 8; // work distribution (see tile_order_kernel)
+    bool pruned = false;
+};
+
+static int plan_render(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id, void *d_rgb_i32, void *d_t,
+                       void *d_stats, void *d_ticks, LaunchPlan *plan) {
     if (!sc) return fail(RTX_ERR_INVALID, "scene is NULL");
     ResolvedParams rp;
     if (int rc = resolve_params(p, &rp)) return rc;
-    rtx::DevRender &r = rp.r;
+    rtx::DevRender &r = plan->r;
+    r = rp.r;
     // what the kernel indexes with must match what it was given
     if (r.layout == RTX_LAYOUT_PACKED_TILES && (d_hit_id || d_t)) return fail(RTX_ERR_INVALID, "hit ids / t are only written in row-major layout");
     r.px = sc->dev.viewport[0] / r.W;     // this->viewport.x / canvasWidth  (scene.hpp:83)
@@ -701,10 +709,12 @@ static int render_device_timed_impl(rtx_scene *sc, const rtx_render_params *p, v
     if (rtx::render_lds_bytes(sc->dev.bvh_depth, block) > 65536)
         return fail(RTX_ERR_UNSUPPORTED, "BVH deeper than 255 levels: traversal stack does not fit LDS");
     r.stack_stride = block;
+    plan->block = block;
     // Tuning knobs (environment overrides are for experiments).
     auto knob = [](const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; };
     // measured per traversal mode: the pruned walk has shorter runs of node steps
     const bool pruned = p->traversal == RTX_TRAVERSAL_PRUNED;
+    plan->pruned = pruned;
     r.w_inner = knob("RTX_W_INNER", pruned ? 3 : 1);
     r.w_leaf = knob("RTX_W_LEAF", pruned ? 4 : 2);
     r.w_shade = knob("RTX_W_SHADE", pruned ? 4 : 2);
@@ -713,112 +723,93 @@ static int render_device_timed_impl(rtx_scene *sc, const rtx_render_params *p, v
     r.also_leaf = knob("RTX_ALSO_LEAF", 16);
     r.also_shade = knob("RTX_ALSO_SHADE", r.also_lanes);
     if (r.w_inner < 1 || r.w_leaf < 1 || r.w_shade < 1) return fail(RTX_ERR_INVALID, "scheduler weights must be positive");
+    plan->grid_blocks = 0;
     if (r.W == 0 || r.H == 0 || r.owned_tiles == 0) return RTX_OK;
-    DeviceGuard guard(sc->device);
-    if (!guard.ok) return fail(RTX_ERR_DEVICE, "cannot select the scene's device");
     // Persistent launch: as many blocks as the chip keeps resident (RTX_WAVES_PER_EU waves per
     // SIMD = that many 256-thread blocks per CU), never more than there are 8x8 blocks of work.
     const uint64_t total_blocks = rtx::render_waves(r);
     if (total_blocks >= (1ull << 26)) return fail(RTX_ERR_UNSUPPORTED, "more than 2^32 pixels in one launch");
     r.total_blocks = (uint32_t)total_blocks;
     const uint32_t wpb = block / 64;
-    uint64_t resident = (uint64_t)sc->cu_count * (uint64_t)knob("RTX_BLOCKS_PER_CU", rtx::render_blocks_per_cu()) * (256 / block);
-    uint64_t grid_blocks = (total_blocks + wpb - 1) / wpb;
-    if (grid_blocks > resident) grid_blocks = resident;
-    // Scratch: a work counter, then (4 + depth) doubles and (1 + 3*depth) ints per resident lane.
-    // The buffers belong to the scene handle and only grow.
-    std::lock_guard<std::mutex> hold_slots(sc->slot_lock);
-    const int slot = (int)(sc->next_slot++ % rtx_scene::kSlots);
-    {
-        const uint64_t lanes = grid_blocks * block;
-        const uint64_t need = rtx::render_scratch_bytes(lanes, r.depth);
-        if (!sc->slot_done[slot]) HIP_TRY(hipEventCreateWithFlags(&sc->slot_done[slot], hipEventDisableTiming));
-        else HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, sc->slot_done[slot], 0));   // the slot's previous frame
-        if (need > sc->scratch_bytes[slot]) {
-            // grow every slot now: an allocation stalls the device, better once than once per slot
-            for (int k = 0; k < rtx_scene::kSlots; k++) {
-                if (need <= sc->scratch_bytes[k]) continue;
-                if (sc->d_scratch[k]) HIP_TRY(hipFree(sc->d_scratch[k]));         // waits for launches still using it
-                sc->d_scratch[k] = nullptr;
-                sc->scratch_bytes[k] = 0;
-                HIP_TRY(hipMalloc(&sc->d_scratch[k], need));
-                sc->scratch_bytes[k] = need;
-            }
-        }
-        r.work = (uint32_t *)sc->d_scratch[slot];
-        r.scratch_lanes = lanes;
-        r.scratch_f64 = (double *)((char *)sc->d_scratch[slot] + 1024);
-        r.scratch_i32 = (int32_t *)((char *)r.scratch_f64 + lanes * (4 + (uint64_t)r.depth) * 8);
-        HIP_TRY(hipMemsetAsync(r.work, 0, 1024, (hipStream_t)stream));
-    }
+    const uint64_t resident = (uint64_t)sc->cu_count * (uint64_t)knob("RTX_BLOCKS_PER_CU", rtx::render_blocks_per_cu()) * (256 / block);
+    plan->grid_blocks = std::min<uint64_t>((total_blocks + wpb - 1) / wpb, std::max<uint64_t>(resident, 1));
     // Work queues.  The frame's tiles are grouped into macro tiles (RTX_MACRO x RTX_MACRO tiles of
     // screen neighbours) and the macro tiles dealt to 8 queues, one per XCD; a wave serves its own
-    // XCD's queue first.  The layout depends only on the launch geometry and is kept on the device
-    // until that changes.
-    {
-        const int n_queues = knob("RTX_XCD_QUEUES", 1) ? 8 : 1;
-        const int macro = std::max(1, knob("RTX_MACRO", 8));
-        const std::vector<int64_t> key = {r.W, r.H, r.tile_w, r.tile_h, r.tile_rank, r.tile_count, n_queues, macro};
-        if (key != sc->order_key) {
-            const uint32_t owned = (uint32_t)r.owned_tiles;
-            std::vector<std::vector<uint32_t>> per_queue(n_queues);
-            const int macros_x = (r.tiles_x + macro - 1) / macro;
-            // macro tiles in row-major order, dealt round-robin with a skew per macro row
-            std::vector<std::vector<uint32_t>> per_macro((size_t)macros_x * ((r.tiles_y + macro - 1) / macro));
-            for (uint32_t lt = 0; lt < owned; lt++) {
-                const uint32_t tile = r.tile_count > 1 ? lt * (uint32_t)r.tile_count + (uint32_t)r.tile_rank : lt;
-                const int tx = (int)(tile % (uint32_t)r.tiles_x), ty = (int)(tile / (uint32_t)r.tiles_x);
-                per_macro[(size_t)(ty / macro) * macros_x + tx / macro].push_back(lt);
-            }
-            for (size_t m = 0; m < per_macro.size(); m++) {
-                const int mx = (int)(m % macros_x), my = (int)(m / macros_x);
-                auto &q = per_queue[(mx + 3 * my) % n_queues];
-                q.insert(q.end(), per_macro[m].begin(), per_macro[m].end());
-            }
-            std::vector<uint32_t> order(9, 0);
-            for (int q = 0; q < 8; q++) {
-                if (q < n_queues) order.insert(order.end(), per_queue[q].begin(), per_queue[q].end());
-                order[q + 1] = (uint32_t)(order.size() - 9);
-            }
-            const uint64_t bytes = order.size() * 4;
-            if (bytes > sc->order_capacity) {
-                if (sc->d_order) HIP_TRY(hipFree(sc->d_order));
-                sc->d_order = nullptr;
-                sc->order_capacity = 0;
-                HIP_TRY(hipMalloc(&sc->d_order, bytes));
-                sc->order_capacity = bytes;
-            }
-            // earlier launches, on any stream, may still be reading the previous layout
-            HIP_TRY(hipDeviceSynchronize());
-            HIP_TRY(hipMemcpy(sc->d_order, order.data(), bytes, hipMemcpyHostToDevice));
-            sc->order_key = key;
-        }
-        r.tile_order = (const uint32_t *)sc->d_order;
-        r.n_queues = (uint32_t)n_queues;
+    // XCD's queue first.
+    plan->n_queues = knob("RTX_XCD_QUEUES", 1) ? 8 : 1;
+    plan->macro = std::min(64, std::max(1, knob("RTX_MACRO", 8)));
+    r.n_queues = (uint32_t)plan->n_queues;
+    return RTX_OK;
+}
 
+// Points the launch at its scratch memory: [work counters][work-queue table][per-lane arrays].
+static void bind_scratch(LaunchPlan *plan, void *base) {
+    rtx::DevRender &r = plan->r;
+    const uint64_t lanes = plan->grid_blocks * plan->block;
+    r.work = (uint32_t *)base;
+    r.tile_order = (const uint32_t *)((char *)base + rtx::kScratchHeaderBytes);
+    r.scratch_lanes = lanes;
+    r.scratch_f64 = (double *)((char *)base + rtx::kScratchHeaderBytes + rtx::render_order_bytes(r, plan->macro));
+    r.scratch_i32 = (int32_t *)((char *)r.scratch_f64 + lanes * (4 + (uint64_t)r.depth) * 8);
+}
+
+static int render_device_timed_impl(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id, void *d_rgb_i32, void *d_t,
+                            void *d_stats, void *d_ticks, void *stream) {
+    LaunchPlan plan;
+    if (int rc = plan_render(sc, p, d_rgb_u8, d_hit_id, d_rgb_i32, d_t, d_stats, d_ticks, &plan)) return rc;
+    if (plan.grid_blocks == 0) return RTX_OK;
+    rtx::DevRender &r = plan.r;
+    const hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(sc->device);
+    if (!guard.ok) return fail(RTX_ERR_DEVICE, "cannot select the scene's device");
+    // Scratch belongs to the scene handle and only grows.  kSlots copies are used in turn; a launch is
+    // ordered behind the previous user of its slot through the slot's event.
+    std::lock_guard<std::mutex> hold_slots(sc->slot_lock);
+    const int slot = (int)(sc->next_slot++ % rtx_scene::kSlots);
+    const uint64_t need = rtx::kScratchHeaderBytes + rtx::render_order_bytes(r, plan.macro) +
+                          plan.grid_blocks * plan.block * rtx::render_lane_bytes(r.depth);
+    if (!sc->slot_done[slot]) HIP_TRY(hipEventCreateWithFlags(&sc->slot_done[slot], hipEventDisableTiming));
+    else HIP_TRY(hipStreamWaitEvent(st, sc->slot_done[slot], 0));   // the slot's previous frame
+    if (need > sc->scratch_bytes[slot]) {
+        // grow every slot now: an allocation stalls the device, better once than once per slot
+        for (int k = 0; k < rtx_scene::kSlots; k++) {
+            if (need <= sc->scratch_bytes[k]) continue;
+            if (sc->d_scratch[k]) HIP_TRY(hipFree(sc->d_scratch[k]));         // waits for launches still using it
+            sc->d_scratch[k] = nullptr;
+            sc->scratch_bytes[k] = 0;
+            sc->slot_key[k].clear();
+            HIP_TRY(hipMalloc(&sc->d_scratch[k], need));
+            sc->scratch_bytes[k] = need;
+        }
+    }
+    bind_scratch(&plan, sc->d_scratch[slot]);
+    HIP_TRY(hipMemsetAsync(r.work, 0, rtx::kScratchHeaderBytes, st));
+    // The work-queue table depends only on the launch geometry: the slot keeps it until a launch with
+    // another geometry (or a smaller lane count, which moves nothing: the table sits in front) uses it.
+    const std::vector<int64_t> key = {r.W, r.H, r.tile_w, r.tile_h, r.tile_rank, r.tile_count, plan.n_queues, plan.macro};
+    if (key != sc->slot_key[slot]) {
+        HIP_TRY(rtx::launch_tile_order((uint32_t *)r.tile_order, r, plan.macro, plan.n_queues, st));
+        sc->slot_key[slot] = key;
     }
     // Diagnostics: RTX_WAVE_LOG=<file> records every wave's start/end tick (100 MHz) of this
     // launch and writes them as raw u64 pairs.  Synchronous; never set in production.
     const char *log_path = getenv("RTX_WAVE_LOG");
-    unsigned long long *d_log = nullptr;
-    uint64_t n_waves = 0;
+    struct DeviceBuffer { void *p = nullptr; ~DeviceBuffer() { (void)hipFree(p); } } log;
+    const uint64_t n_waves = plan.grid_blocks * (plan.block / 64);
     if (log_path && *log_path) {
-        n_waves = grid_blocks * wpb;
-        HIP_TRY(hipMalloc((void **)&d_log, n_waves * 16));
-        HIP_TRY(hipMemset(d_log, 0, n_waves * 16));
-        r.wave_log = d_log;
+        HIP_TRY(hipMalloc(&log.p, n_waves * 16));
+        HIP_TRY(hipMemset(log.p, 0, n_waves * 16));
+        r.wave_log = (unsigned long long *)log.p;
     }
     if (d_ticks) {
-        HIP_TRY(hipMemsetAsync(d_ticks, 0xff, 8, (hipStream_t)stream));
-        HIP_TRY(hipMemsetAsync((char *)d_ticks + 8, 0x00, 8, (hipStream_t)stream));
+        HIP_TRY(hipMemsetAsync(d_ticks, 0xff, 8, st));
+        HIP_TRY(hipMemsetAsync((char *)d_ticks + 8, 0x00, 8, st));
     }
-    HIP_TRY(rtx::launch_render(sc->dev, r, p->traversal == RTX_TRAVERSAL_PRUNED, d_stats != nullptr, block, (uint32_t)grid_blocks,
-                               (hipStream_t)stream));
-    HIP_TRY(hipEventRecord(sc->slot_done[slot], (hipStream_t)stream));
-    if (d_log) {
+    HIP_TRY(rtx::launch_render(sc->dev, r, plan.pruned, d_stats != nullptr, plan.block, (uint32_t)plan.grid_blocks, st));
+    HIP_TRY(hipEventRecord(sc->slot_done[slot], st));
+    if (log.p) {
         std::vector<unsigned long long> h(n_waves * 2);
-        HIP_TRY(hipMemcpy(h.data(), d_log, n_waves * 16, hipMemcpyDeviceToHost));
-        (void)hipFree(d_log);
+        HIP_TRY(hipMemcpy(h.data(), log.p, n_waves * 16, hipMemcpyDeviceToHost));
         if (FILE *f = fopen(log_path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }
     return RTX_OK;

@@ -20,11 +20,19 @@ inline size_t render_lds_bytes(int32_t bvh_depth, uint32_t block_threads) {
 inline uint64_t render_waves(const DevRender &rp) {
     return (uint64_t)(rp.tile_w / 8) * (uint64_t)(rp.tile_h / 8) * (uint64_t)rp.owned_tiles;
 }
-// scratch a render launch needs: per resident lane (4 + depth) doubles and (1 + 3 * depth) ints,
-// after 1 KiB for the work counters
-inline uint64_t render_scratch_bytes(uint64_t lanes, int32_t depth) {
-    return 1024 + lanes * ((4 + (uint64_t)depth) * 8 + (1 + 3 * (uint64_t)depth) * 4);
+
+// The scratch buffer of a render launch: 1 KiB of work counters, the work-queue table
+// (9 + owned tiles + macro tiles words, see tile_order_kernel), then the per-lane arrays.
+constexpr uint64_t kScratchHeaderBytes = 1024;
+inline uint64_t render_order_words(const DevRender &rp, int macro) {
+    const uint64_t macros = (uint64_t)((rp.tiles_x + macro - 1) / macro) * (uint64_t)((rp.tiles_y + macro - 1) / macro);
+    return 9 + (uint64_t)rp.owned_tiles + macros;
 }
+inline uint64_t render_order_bytes(const DevRender &rp, int macro) { return (render_order_words(rp, macro) * 4 + 255) / 256 * 256; }
+inline uint64_t render_lane_bytes(int32_t depth) { return (4 + (uint64_t)depth) * 8 + (1 + 3 * (uint64_t)depth) * 4; }
+
+// Builds the work-queue table of `rp` at d_order (render_order_words() words) on the stream.
+hipError_t launch_tile_order(uint32_t *d_order, const DevRender &rp, int macro, int n_queues, hipStream_t st);
 
 // 256-thread blocks of the render kernel one CU keeps resident (= its waves per SIMD)
 int render_blocks_per_cu();

@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "device_layout.h"
 #include "rtx_kernels.h"
 
@@ -859,7 +861,67 @@ __global__ void __launch_bounds__(256) untile_kernel(const uint8_t *__restrict__
     for (int b = 0; b < bpp; b++) dst[k * (uint32_t)bpp + b] = src[s + b];
 }
 
+// The work-queue table of a launch (layout: DevRender::tile_order), built where it is read.
+// The launch's local tiles are grouped into macro tiles of macro x macro screen neighbours; macro
+// tile (mx, my) belongs to queue (mx + 3 my) mod n_queues; a queue lists its macro tiles in
+// row-major order and a macro tile its own tiles in row-major order.  One block: a count per macro
+// tile, one thread per queue turns the counts into offsets, then every macro tile writes its tiles.
+// `order` has room for 9 + owned tiles + macro tiles words (the counts live behind the table).
+__global__ void __launch_bounds__(1024) tile_order_kernel(uint32_t *order, int tiles_x, int tiles_y, int tile_rank, int tile_count,
+                                                          uint32_t owned, int macro, int n_queues) {
+    const int macros_x = (tiles_x + macro - 1) / macro, macros_y = (tiles_y + macro - 1) / macro;
+    const int n_macros = macros_x * macros_y;
+    uint32_t *cnt = order + 9u + owned;
+    __shared__ uint32_t q_total[8], q_base[9];
+    for (int pass = 0; pass < 2; pass++) {
+        for (int m = (int)threadIdx.x; m < n_macros; m += (int)blockDim.x) {
+            const int mx = m % macros_x, my = m / macros_x;
+            const int tx1 = min(tiles_x, (mx + 1) * macro), ty1 = min(tiles_y, (my + 1) * macro);
+            uint32_t k = pass ? 9u + q_base[(mx + 3 * my) % n_queues] + cnt[m] : 0u;
+            for (int ty = my * macro; ty < ty1; ty++)
+                for (int tx = mx * macro; tx < tx1; tx++) {
+                    const uint32_t tile = (uint32_t)ty * (uint32_t)tiles_x + (uint32_t)tx;
+                    if (tile_count > 1 && tile % (uint32_t)tile_count != (uint32_t)tile_rank) continue;
+                    if (pass) order[k] = tile_count > 1 ? tile / (uint32_t)tile_count : tile;
+                    k++;
+                }
+            if (!pass) cnt[m] = k;
+        }
+        __syncthreads();
+        if (!pass) {
+            if ((int)threadIdx.x < n_queues) {          // counts -> offsets inside the queue
+                uint32_t run = 0;
+                for (int m = 0; m < n_macros; m++)
+                    if ((m % macros_x + 3 * (m / macros_x)) % n_queues == (int)threadIdx.x) {
+                        const uint32_t c = cnt[m];
+                        cnt[m] = run;
+                        run += c;
+                    }
+                q_total[threadIdx.x] = run;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t run = 0;
+                for (int q = 0; q < 8; q++) {
+                    q_base[q] = run;
+                    order[q] = run;
+                    if (q < n_queues) run += q_total[q];
+                }
+                q_base[8] = run;
+                order[8] = run;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace
+
+hipError_t launch_tile_order(uint32_t *d_order, const DevRender &rp, int macro, int n_queues, hipStream_t st) {
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, d_order, rp.tiles_x, rp.tiles_y, rp.tile_rank, rp.tile_count,
+                       (uint32_t)rp.owned_tiles, macro, n_queues);
+    return hipGetLastError();
+}
 
 int render_blocks_per_cu() { return RTX_WAVES_PER_EU; }
 
