@@ -107,7 +107,7 @@ EXPORTS = (
     "rtx_save_ppm", "rtx_save_png", "rtx_selftest_division", "rtx_selftest_pow", "rtx_selftest_sqrt", "rtx_last_error", "rtx_version",
     "rtx_host_scene_load_obj_ex", "rtx_host_scene_standin_ex",
     "rtx_bvh_build", "rtx_host_scene_rebuild_bvh", "rtx_scene_create_with_builder", "rtx_scene_build_seconds",
-    "rtx_scene_bvh_nodes", "rtx_scene_bvh_depth",
+    "rtx_scene_bvh_nodes", "rtx_scene_bvh_depth", "rtx_render_device_noalloc",
 )
 
 _lib = None
@@ -164,6 +164,7 @@ def lib() -> C.CDLL:
     L.rtx_render.argtypes = [vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]
     L.rtx_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, vp, vp, vp]
     L.rtx_render_device_timed.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, vp, vp, vp, vp]
+    L.rtx_render_device_noalloc.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, vp, vp, vp]
     L.rtx_untile.argtypes = [C.POINTER(RenderParams), C.c_int32, vp, vp, C.c_int32, vp]
     L.rtx_save_ppm.argtypes = [C.c_char_p, C.c_int32, C.c_int32, vp]
     L.rtx_save_png.argtypes = [C.c_char_p, C.c_int32, C.c_int32, vp]
@@ -432,6 +433,11 @@ class Scene:
         receive the kernel's first-block start and last-block end on the device's 100 MHz clock."""
         _check(lib().rtx_render_device_timed(self._h, C.byref(params), rgb_u8 or None, hit or None, rgb_i32 or None,
                                              t or None, stats or None, ticks or None, stream or None))
+
+    def render_device_noalloc(self, params: RenderParams, *, rgb_u8=0, hit=0, rgb_i32=0, t=0, stats=0, stream=0) -> None:
+        """render_device() through the entry point that allocates nothing (scratch in the library's fixed device array)."""
+        _check(lib().rtx_render_device_noalloc(self._h, C.byref(params), rgb_u8 or None, hit or None, rgb_i32 or None,
+                                               t or None, stats or None, stream or None))
 
     def close(self) -> None:
         if self._h:

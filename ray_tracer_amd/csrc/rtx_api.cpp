@@ -815,6 +815,34 @@ static int render_device_timed_impl(rtx_scene *sc, const rtx_render_params *p, v
     return RTX_OK;
 }
 
+// The same launch with every byte of its scratch in the library's file-scope device array
+// (rtx::noalloc_scratch): no allocation, no event, no host-side state.  A frame that does not fit
+// the array whole runs with fewer resident lanes; one whose work-queue table alone does not fit is
+// refused.
+static int render_device_noalloc_impl(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id, void *d_rgb_i32,
+                                      void *d_t, void *d_stats, void *stream) {
+    LaunchPlan plan;
+    if (int rc = plan_render(sc, p, d_rgb_u8, d_hit_id, d_rgb_i32, d_t, d_stats, nullptr, &plan)) return rc;
+    if (plan.grid_blocks == 0) return RTX_OK;
+    rtx::DevRender &r = plan.r;
+    const hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(sc->device);
+    if (!guard.ok) return fail(RTX_ERR_DEVICE, "cannot select the scene's device");
+    void *base = nullptr;
+    HIP_TRY(rtx::noalloc_scratch(sc->device, &base));
+    const uint64_t fixed = rtx::kScratchHeaderBytes + rtx::render_order_bytes(r, plan.macro);
+    const uint64_t per_block = plan.block * rtx::render_lane_bytes(r.depth);
+    if (fixed + per_block > rtx::kNoallocScratchBytes)
+        return fail(RTX_ERR_UNSUPPORTED, "rtx_render_device_noalloc: the frame has more tiles than the fixed scratch array's "
+                                         "work-queue table holds (32 MiB in all; use larger tiles or rtx_render_device)");
+    plan.grid_blocks = std::min<uint64_t>(plan.grid_blocks, (rtx::kNoallocScratchBytes - fixed) / per_block);
+    bind_scratch(&plan, base);
+    HIP_TRY(hipMemsetAsync(r.work, 0, rtx::kScratchHeaderBytes, st));       // the last call's counters
+    HIP_TRY(rtx::launch_tile_order((uint32_t *)r.tile_order, r, plan.macro, plan.n_queues, st));
+    HIP_TRY(rtx::launch_render(sc->dev, r, plan.pruned, d_stats != nullptr, plan.block, (uint32_t)plan.grid_blocks, st));
+    return RTX_OK;
+}
+
 // A device buffer and its pinned twin on the host, grown on demand and kept with the scene.
 static hipError_t grow_pair(void **dev, void **host, uint64_t *have, uint64_t need) {
     if (need <= *have) return hipSuccess;
@@ -1091,6 +1119,11 @@ int rtx_scene_create_with_builder(const rtx_scene_desc *desc, int32_t builder, r
 int rtx_render_device_timed(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id, void *d_rgb_i32, void *d_t,
                             void *d_stats, void *d_ticks, void *stream) {
     return guarded([&]() -> int { return render_device_timed_impl(sc, p, d_rgb_u8, d_hit_id, d_rgb_i32, d_t, d_stats, d_ticks, stream); });
+}
+
+int rtx_render_device_noalloc(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id, void *d_rgb_i32, void *d_t,
+                              void *d_stats, void *stream) {
+    return guarded([&]() -> int { return render_device_noalloc_impl(sc, p, d_rgb_u8, d_hit_id, d_rgb_i32, d_t, d_stats, stream); });
 }
 
 int rtx_render(rtx_scene *sc, const rtx_render_params *p, uint8_t *rgb_out, int32_t *hit_id_out, rtx_stats *stats) {

@@ -31,6 +31,11 @@ inline uint64_t render_order_words(const DevRender &rp, int macro) {
 inline uint64_t render_order_bytes(const DevRender &rp, int macro) { return (render_order_words(rp, macro) * 4 + 255) / 256 * 256; }
 inline uint64_t render_lane_bytes(int32_t depth) { return (4 + (uint64_t)depth) * 8 + (1 + 3 * (uint64_t)depth) * 4; }
 
+// Size of the file-scope device array behind rtx_render_device_noalloc, per GPU.
+constexpr uint64_t kNoallocScratchBytes = 32ull << 20;
+// Device address of that array on `device`, which must be current (looked up once per device).
+hipError_t noalloc_scratch(int device, void **ptr);
+
 // Builds the work-queue table of `rp` at d_order (render_order_words() words) on the stream.
 hipError_t launch_tile_order(uint32_t *d_order, const DevRender &rp, int macro, int n_queues, hipStream_t st);
 

@@ -915,7 +915,32 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(uint32_t *order, int t
     }
 }
 
+// Scratch of the entry point that allocates nothing (rtx_render_device_noalloc): work counters,
+// work-queue table and per-lane shading scratch of ONE launch.  Every GPU the library runs on
+// holds its own copy at its own address until the process ends.
+static __device__ __align__(256) unsigned char scratch[kNoallocScratchBytes];
+
 }  // namespace
+
+// Device address of `scratch` on `device` (which must be the current device).  In host code the
+// array's name is only a handle for hipGetSymbolAddress; the address it returns is what kernels,
+// memsets and copies are given.  Looked up once per device.
+hipError_t noalloc_scratch(int device, void **ptr) {
+    constexpr int kMaxDevices = 64;
+    static void *addr[kMaxDevices] = {};
+    static std::mutex lock;
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> hold(lock);
+    if (!addr[device]) {
+        void *p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        addr[device] = p;
+    }
+    *ptr = addr[device];
+    return hipSuccess;
+}
 
 hipError_t launch_tile_order(uint32_t *d_order, const DevRender &rp, int macro, int n_queues, hipStream_t st) {
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, d_order, rp.tiles_x, rp.tiles_y, rp.tile_rank, rp.tile_count,
