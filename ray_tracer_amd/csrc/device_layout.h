@@ -29,6 +29,11 @@ struct alignas(64) DevNode {
 };
 static_assert(sizeof(DevNode) == 64, "DevNode");
 
+// bit 30 of a node reference: a pair of the top table (bits 15..0 = its index), not a slot of `nodes`
+constexpr uint32_t kTopFlag = 0x40000000u;
+// pairs the table may hold at most (its queue lives in the build kernel's LDS)
+constexpr uint32_t kTopPairsMax = 512;
+
 struct alignas(128) DevTri {
     double v0[3], v1[3], v2[3];
     double n[3];       // Triangle::normal, computed on the host (triangle.hpp:21-23)
@@ -57,6 +62,12 @@ struct DevScene {
     const DevTri *tris;
     const DevMat *mats;
     const DevLight *lights;   // point lights first, then directional
+    // The top of the tree once more, for the render kernel's LDS: `n_top_pairs` sibling pairs
+    // in breadth-first order (pair 0 = slots 0 and 1), 128 bytes each.  Inside it an inner
+    // child whose own pair is in the table carries kTopFlag | pair index as `first`, and
+    // pad[0] of a pair's first record holds the pair's slot in `nodes`.
+    const DevNode *top;
+    uint32_t n_top_pairs, top_pad;
     uint32_t n_nodes, n_tris, n_point, n_dir;
     double cam[3];
     double viewport[3];

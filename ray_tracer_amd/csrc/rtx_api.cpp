@@ -31,7 +31,7 @@ struct rtx_host_scene {
 struct rtx_scene {
     int device = 0;
     rtx::DevScene dev{};
-    void *d_nodes = nullptr, *d_tris = nullptr, *d_mats = nullptr, *d_lights = nullptr;
+    void *d_nodes = nullptr, *d_tris = nullptr, *d_mats = nullptr, *d_lights = nullptr, *d_top = nullptr;
     // Per-lane scratch of the render kernel, kept between frames and grown on demand.  kSlots
     // copies, used in turn, let that many frames be in flight on different streams (the end of a
     // frame, when lanes run dry, then overlaps the start of the next one); slot_done[k] orders a
@@ -205,6 +205,25 @@ int finish_device_scene(rtx_scene *sc, const SceneCommon &c, uint64_t n, uint64_
     sincos(rz, &d.sz, &d.cz);
     d.ambient = c.ambient;
     d.bvh_depth = bvh_depth;
+    // The top of the tree for the render kernel's LDS: as many sibling pairs as a block has room for
+    // behind its traversal stacks (block size as plan_render chooses it).
+    uint32_t block = 256;
+    while (block > 64 && rtx::render_lds_bytes(bvh_depth, block) > 65536) block >>= 1;
+    const char *cap = getenv("RTX_TOP_PAIRS");          // experiments: fewer pairs, 0 = none
+    uint32_t pairs = rtx::render_top_pairs(bvh_depth, block, rtx::render_blocks_per_cu());
+    if (cap && *cap) pairs = std::min<uint32_t>(pairs, (uint32_t)atoi(cap));
+    d.top = nullptr;
+    d.n_top_pairs = 0;
+    if (pairs) {
+        HIP_TRY(hipMalloc(&sc->d_top, (size_t)pairs * 128 + 16));
+        uint32_t *d_count = (uint32_t *)((char *)sc->d_top + (size_t)pairs * 128);
+        HIP_TRY(rtx::launch_top_table(d.nodes, (rtx::DevNode *)sc->d_top, pairs, d_count, nullptr));
+        uint32_t n = 0;
+        HIP_TRY(hipMemcpy(&n, d_count, sizeof n, hipMemcpyDeviceToHost));
+        d.top = (const rtx::DevNode *)sc->d_top;
+        d.n_top_pairs = n;
+        sc->bytes += (uint64_t)pairs * 128;
+    }
     return RTX_OK;
 }
 
@@ -633,6 +652,7 @@ void rtx_scene_destroy(rtx_scene *sc) {
     (void)hipFree(sc->d_tris);
     (void)hipFree(sc->d_mats);
     (void)hipFree(sc->d_lights);
+    (void)hipFree(sc->d_top);
     for (int k = 0; k < rtx_scene::kSlots; k++) {
         (void)hipFree(sc->d_scratch[k]);
         if (sc->slot_done[k]) (void)hipEventDestroy(sc->slot_done[k]);

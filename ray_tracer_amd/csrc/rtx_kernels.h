@@ -12,10 +12,22 @@ namespace rtx {
 // must equal RTX_LAYOUT_PACKED_TILES in include/rtx.h (checked in rtx_api.cpp)
 constexpr int RTX_LAYOUT_PACKED_TILES_ = 1;
 
-// LDS bytes a render launch needs per block: one u32 traversal-stack slot per tree level per lane.
+// LDS bytes of a render block's traversal stacks: one u32 slot per tree level per lane.
 inline size_t render_lds_bytes(int32_t bvh_depth, uint32_t block_threads) {
     return (size_t)(bvh_depth + 1) * block_threads * sizeof(uint32_t);
 }
+// Sibling pairs of the top of the tree a render block keeps in LDS behind its stacks: what is left of
+// the block's share of a CU's 160 KiB (render_blocks_per_cu() blocks of 256 threads, or their
+// equivalent in smaller blocks, are resident), 128 bytes a pair.
+inline uint32_t render_top_pairs(int32_t bvh_depth, uint32_t block_threads, int blocks_per_cu) {
+    const size_t share = (size_t)163840 / (size_t)blocks_per_cu * block_threads / 256;
+    const size_t stack = render_lds_bytes(bvh_depth, block_threads);
+    if (stack + 128 > share) return 0;
+    const size_t pairs = (share - stack) / 128;
+    return (uint32_t)(pairs < kTopPairsMax ? pairs : kTopPairsMax);
+}
+// Builds the table (DevScene::top) from the flattened nodes; *d_count receives the pairs written (<= max_pairs).
+hipError_t launch_top_table(const DevNode *d_nodes, DevNode *d_top, uint32_t max_pairs, uint32_t *d_count, hipStream_t st);
 // waves of a render launch: one per 8x8-pixel block of every owned tile
 inline uint64_t render_waves(const DevRender &rp) {
     return (uint64_t)(rp.tile_w / 8) * (uint64_t)(rp.tile_h / 8) * (uint64_t)rp.owned_tiles;

@@ -379,11 +379,13 @@ struct Scratch {
 struct Hot {
     const DevNode *nodes;
     const DevTri *tris;
+    const d2 *top;       // LDS copy of the top of the tree (DevScene::top), 8 pieces of 16 bytes per pair
+    uint32_t root_ref;   // where a walk starts: kTopFlag | 0 with a table, else slot 0
     uint32_t n_point;
     int32_t w_inner, w_leaf, w_shade, tail_lanes, also_lanes, also_leaf, also_shade;
 };
 
-__device__ __forceinline__ void start_query(Lane &L, const DevScene &sc, bool prune) {
+__device__ __forceinline__ void start_query(Lane &L, const DevScene &sc, bool prune, uint32_t root_ref) {
     L.rd = make_raydiv(L.o, L.r, sc.fast_div_ok != 0);
     L.slack = prune ? slack_point(L.o, sc.scene_scale) : 0.0;
     // no accepted t can reach tmax, so tmax is the first limit
@@ -392,7 +394,7 @@ __device__ __forceinline__ void start_query(Lane &L, const DevScene &sc, bool pr
     L.best_pos = -1;
     // slot 0 holds a box no ray enters and slot 1 the root: the walk starts as the pair
     // test of (0, 1), which is the root's own slab test (bvh.hpp:174)
-    L.first = 0;
+    L.first = root_ref;
     L.count = 0;
     L.sp = 0;
     L.state = ST_INNER;
@@ -431,10 +433,22 @@ __device__ __forceinline__ void pop_node(Lane &L, const DevNode *nodes, const ui
 template <bool PRUNE, bool STATS>
 __device__ __forceinline__ void inner_step(Lane &L, const Hot &hot, uint32_t *stack, uint32_t stride, Counters &c) {
     const DevNode *nodes = hot.nodes;
-    // the sibling pair is one 128-byte line: eight 16-byte loads, one round trip
-    const d2 *line = reinterpret_cast<const d2 *>(nodes + L.first);
-    d2 q0 = line[0], q1 = line[1], q2 = line[2], q3 = line[3], q4 = line[4], q5 = line[5], q6 = line[6], q7 = line[7];
-    pin(q0); pin(q1); pin(q2); pin(q3); pin(q4); pin(q5); pin(q6); pin(q7);
+    // the sibling pair is one 128-byte line: eight 16-byte loads, one round trip -- to LDS for a pair
+    // of the top table (every walk starts there, and the vector memory path is what the kernel waits
+    // for), else to memory
+    d2 q0, q1, q2, q3, q4, q5, q6, q7;
+    const bool in_top = (L.first & kTopFlag) != 0;
+    if (in_top) {
+        const d2 *line = hot.top + (L.first & 0xFFFFu) * 8u;
+        q0 = line[0]; q1 = line[1]; q2 = line[2]; q3 = line[3]; q4 = line[4]; q5 = line[5]; q6 = line[6]; q7 = line[7];
+    } else {
+        const d2 *line = reinterpret_cast<const d2 *>(nodes + L.first);
+        q0 = line[0]; q1 = line[1]; q2 = line[2]; q3 = line[3]; q4 = line[4]; q5 = line[5]; q6 = line[6]; q7 = line[7];
+        pin(q0); pin(q1); pin(q2); pin(q3); pin(q4); pin(q5); pin(q6); pin(q7);
+    }
+    const bool root_pair = (L.first & ~kTopFlag) == 0;                   // slots (0, 1)
+    // the pair's slot in `nodes` (a table pair carries it in its first record's padding)
+    const uint32_t pair_slot = in_top ? (uint32_t)__double2loint(q3.y) : L.first;
     const double a_lo[3] = {q0.x, q0.y, q1.x}, a_hi[3] = {q1.y, q2.x, q2.y};
     const double b_lo[3] = {q4.x, q4.y, q5.x}, b_hi[3] = {q5.y, q6.x, q6.y};
     double ta, tb;
@@ -443,7 +457,7 @@ __device__ __forceinline__ void inner_step(Lane &L, const Hot &hot, uint32_t *st
         const bool zx = L.rd.flags & RD_ZX;
         slab_one_nz(a_lo, a_hi, L.o, L.r, L.rd, L.lim, zx, &ha, &beyond_a, &ta);
         slab_one_nz(b_lo, b_hi, L.o, L.r, L.rd, L.lim, zx, &hb, &beyond_b, &tb);
-        ha = ha && L.first != 0;            // slot 0 is the box no ray enters
+        ha = ha && !root_pair;              // slot 0 is the box no ray enters
     } else if (L.rd.flags & RD_OK) {
         ha = slab_fast(a_lo, a_hi, L.o, L.r, L.rd, L.lim, &ta, &beyond_a);
         hb = slab_fast(b_lo, b_hi, L.o, L.r, L.rd, L.lim, &tb, &beyond_b);
@@ -452,7 +466,7 @@ __device__ __forceinline__ void inner_step(Lane &L, const Hot &hot, uint32_t *st
         hb = slab(b_lo, b_hi, L.o, L.r, L.lim, &tb, &beyond_b);
     }
     if (STATS) {
-        c.v[C_NODES] += L.first ? 2 : 1;      // slot 0 is not a node of the tree
+        c.v[C_NODES] += root_pair ? 1 : 2;    // slot 0 is not a node of the tree
         c.v[C_BOXHITS] += (ha ? 1 : 0) + (hb ? 1 : 0);
     }
     if (PRUNE) {
@@ -467,7 +481,7 @@ __device__ __forceinline__ void inner_step(Lane &L, const Hot &hot, uint32_t *st
     const bool take_b = hb && (!ha || (PRUNE && tb < ta));
     if (ha && hb) {
         // the child that is not taken
-        stack[L.sp << stride] = stack_entry(take_b ? L.first : L.first + 1u, take_b ? af : bf, take_b ? ac : bc);
+        stack[L.sp << stride] = stack_entry(take_b ? pair_slot : pair_slot + 1u, take_b ? af : bf, take_b ? ac : bc);
         L.sp++;
     }
     if (ha || hb) {
@@ -544,7 +558,7 @@ struct PixelSum {
 // A finished query (scene.hpp:89-183).  Leaves the lane with a new query (ST_INNER) or done.
 template <bool PRUNE, bool STATS>
 __device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScene &sc, const DevRender &rp, const Scratch &scr,
-                                           Counters &c) {
+                                           Counters &c, uint32_t root_ref) {
     const uint32_t n_lights = sc.n_point + sc.n_dir;
     const uint32_t kind = path_kind(L.path), s = path_s(L.path);
     uint32_t d = path_d(L.path), li = path_li(L.path);
@@ -606,7 +620,7 @@ __device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScen
             const V3 lv = ld3(sc.lights[li].v);
             L.r = (li < sc.n_point) ? sub(lv, L.o) : lv;
             L.path = make_path(1, d, s, li);
-            start_query(L, sc, PRUNE);
+            start_query(L, sc, PRUNE, root_ref);
             return;
         }
         // Color * double truncates each channel (color.hpp:47-53)
@@ -624,7 +638,7 @@ __device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScen
             const V3 v = {scr.f(0), scr.f(1), scr.f(2)};
             L.r = reflect_ray(v, ld3(sc.tris[pos].n));                  // scene.hpp:119
             L.path = make_path(0, d + 1, s, 0);
-            start_query(L, sc, PRUNE);
+            start_query(L, sc, PRUNE, root_ref);
             return;
         }
     }
@@ -655,7 +669,7 @@ __device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScen
     acc.r += clamp255(cr); acc.g += clamp255(cg); acc.b += clamp255(cb);
     if (s + 1 < (uint32_t)rp.spp) {
         primary_ray(L, sc, rp, (int)(L.pix & 0xFFFFu), (int)(L.pix >> 16), s + 1);
-        start_query(L, sc, PRUNE);
+        start_query(L, sc, PRUNE, root_ref);
         return;
     }
     const int spp = rp.spp;
@@ -692,7 +706,15 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
 
     // the stack of a lane is strided by the block size, a power of two: levels are shifted, not multiplied
     const uint32_t stride = 31u - (uint32_t)__builtin_clz(rp.stack_stride);
-    const Hot hot = {sc.nodes, sc.tris, sc.n_point, rp.w_inner, rp.w_leaf, rp.w_shade, rp.tail_lanes, rp.also_lanes, rp.also_leaf, rp.also_shade};
+    // the top of the tree goes into LDS behind the block's stacks
+    const uint32_t n_top = sc.n_top_pairs;
+    d2 *top_lds = reinterpret_cast<d2 *>(lds + (uint32_t)(sc.bvh_depth + 1) * rp.stack_stride);
+    {
+        const d2 *src = reinterpret_cast<const d2 *>(sc.top);
+        for (uint32_t i = threadIdx.x; i < n_top * 8u; i += blockDim.x) top_lds[i] = src[i];
+        __syncthreads();
+    }
+    const Hot hot = {sc.nodes, sc.tris, top_lds, n_top ? kTopFlag : 0u, sc.n_point, rp.w_inner, rp.w_leaf, rp.w_shade, rp.tail_lanes, rp.also_lanes, rp.also_leaf, rp.also_shade};
     uint32_t *stack = lds + threadIdx.x;
     const Scratch scr = {rp.scratch_f64, rp.scratch_i32, rp.scratch_lanes, gw * 64u + lane};
     Counters c;
@@ -747,7 +769,7 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
         }
         if ((!pick_inner && !pick_leaf) || (all_kinds && n_shade) || n_shade >= hot.also_shade) {
             if (STATS) { const int k = __popcll(__ballot(L.state == ST_SHADE)); if (lane == 0) { rounds[2]++; lane_steps[2] += k; } }
-            if (L.state == ST_SHADE) shade_step<PRUNE, STATS>(L, acc, sc, rp, scr, c);
+            if (L.state == ST_SHADE) shade_step<PRUNE, STATS>(L, acc, sc, rp, scr, c, hot.root_ref);
             // hand pixels to the lanes without one, in lane order
             unsigned long long need = __ballot(L.state == ST_FETCH);
             while (need) {
@@ -791,7 +813,7 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
                                                                         : row * (uint32_t)rp.W + col;
                         acc = {0, 0, 0};
                         primary_ray(L, sc, rp, (int)col, (int)row, 0);
-                        start_query(L, sc, PRUNE);
+                        start_query(L, sc, PRUNE, hot.root_ref);
                     }
                 }
                 const uint32_t n_need = (uint32_t)__popcll(need);
@@ -859,6 +881,27 @@ __global__ void __launch_bounds__(256) untile_kernel(const uint8_t *__restrict__
     uint64_t s = (uint64_t)rank * rank_stride +
                  (((uint64_t)local_tile * (uint32_t)tile_h + (uint32_t)(row % tile_h)) * (uint32_t)tile_w + (uint32_t)(col % tile_w)) * (uint32_t)bpp;
     for (int b = 0; b < bpp; b++) dst[k * (uint32_t)bpp + b] = src[s + b];
+}
+
+// DevScene::top: the first `max_pairs` sibling pairs of the tree in breadth-first order.  One thread:
+// a few hundred records at most, once per scene.
+__global__ void __launch_bounds__(64) top_table_kernel(const DevNode *nodes, DevNode *top, uint32_t max_pairs, uint32_t *count) {
+    __shared__ uint32_t slot_of[kTopPairsMax];
+    if (threadIdx.x != 0) return;
+    if (max_pairs > kTopPairsMax) max_pairs = kTopPairsMax;
+    uint32_t n = 0;
+    if (max_pairs) slot_of[n++] = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t s = slot_of[i];
+        DevNode a = nodes[s], b = nodes[s + 1];
+        // an inner child whose pair still fits is referred to by its place in the table; slot 0 is no node
+        if (s != 0 && a.count == 0 && n < max_pairs) { slot_of[n] = a.first; a.first = kTopFlag | n; n++; }
+        if (b.count == 0 && n < max_pairs) { slot_of[n] = b.first; b.first = kTopFlag | n; n++; }
+        a.pad[0] = s;
+        top[2 * i] = a;
+        top[2 * i + 1] = b;
+    }
+    *count = n;
 }
 
 // The work-queue table of a launch (layout: DevRender::tile_order), built where it is read.
@@ -942,6 +985,11 @@ hipError_t noalloc_scratch(int device, void **ptr) {
     return hipSuccess;
 }
 
+hipError_t launch_top_table(const DevNode *d_nodes, DevNode *d_top, uint32_t max_pairs, uint32_t *d_count, hipStream_t st) {
+    hipLaunchKernelGGL(top_table_kernel, dim3(1), dim3(64), 0, st, d_nodes, d_top, max_pairs, d_count);
+    return hipGetLastError();
+}
+
 hipError_t launch_tile_order(uint32_t *d_order, const DevRender &rp, int macro, int n_queues, hipStream_t st) {
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, d_order, rp.tiles_x, rp.tiles_y, rp.tile_rank, rp.tile_count,
                        (uint32_t)rp.owned_tiles, macro, n_queues);
@@ -954,7 +1002,7 @@ hipError_t launch_render(const DevScene &sc, const DevRender &rp, bool prune, bo
                          uint32_t grid_blocks, hipStream_t st) {
     if (rp.total_blocks == 0 || grid_blocks == 0) return hipSuccess;
     dim3 grid(grid_blocks), block(block_threads);
-    const size_t lds = render_lds_bytes(sc.bvh_depth, block_threads);
+    const size_t lds = render_lds_bytes(sc.bvh_depth, block_threads) + (size_t)sc.n_top_pairs * 128;
     if (prune && stats) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, lds, st, sc, rp);
     else if (prune) hipLaunchKernelGGL((render_kernel<true, false>), grid, block, lds, st, sc, rp);
     else if (stats) hipLaunchKernelGGL((render_kernel<false, true>), grid, block, lds, st, sc, rp);
