@@ -20,12 +20,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
+L2_PEAK_GBS = 34500.0   # aggregate of the eight XCDs' L2s
+CLOCK_GHZ = 2.4
 
 
-def profiled_traffic(workload_key):
-    """HBM bytes per launch of the render kernel from the committed PMC passes (profiles/traffic.json,
-    written by tools/pmc_summary.py): FETCH_SIZE is doubled as the gfx950 note on that counter
-    prescribes, WRITE_SIZE taken as is; both are reported in KiB by rocprofv3."""
+def profiled_counters(workload_key):
+    """Counters per launch of the render kernel from the committed PMC passes (profiles/traffic.json, written by
+    tools/pmc_summary.py from `rocprofv3 --pmc` runs of the same frame): HBM bytes = FETCH_SIZE doubled, as the gfx950
+    note on that counter prescribes, + WRITE_SIZE (both reported in KiB); wave-level VALU instructions = SQ_INSTS_VALU.
+    None when the table has no entry for this workload."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[workload_key]
         return {"bytes": int((2 * t["FETCH_SIZE_KiB"] + t["WRITE_SIZE_KiB"]) * 1024), "source": t["source"],
@@ -37,7 +40,14 @@ def profiled_traffic(workload_key):
 def cpu_baseline(scene_name, n_tris, W, H, depth, obj_path):
     """Times the CPU path on the host cores: oracle/_ref/ref_bvh (the reference's own headers,
     compiled in the build container) when present, else the oracle restatement."""
-    cores = min(16, os.cpu_count() or 1)
+    # A one-GPU box gives a job 16 host cores, whatever `nproc` says about the machine (many times as many): the
+    # baseline runs on that share, as the reference runs on all of ITS cores (8 threads, src/main.cpp:35)
+    nproc = os.cpu_count() or 1
+    try:
+        share = len(os.sched_getaffinity(0))
+    except AttributeError:
+        share = nproc
+    cores = max(1, min(share, int(os.environ.get("RTX_CPU_BASELINE_THREADS", "16"))))
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_bvh")
     cli = os.path.join(ROOT, "oracle", "oracle_cli")
     scene_root = os.path.dirname(os.path.dirname(obj_path))
@@ -62,8 +72,8 @@ def cpu_baseline(scene_name, n_tris, W, H, depth, obj_path):
 
         secs = frames(cmd)
         # the reference times three frames in a row (src/main.cpp:42-61); the median one counts here
-        res = {"kind": kind, "cores": cores, "seconds": sorted(secs)[len(secs) // 2], "all": secs, "frames": len(secs),
-               "cmd": os.path.basename(cmd[0])}
+        res = {"kind": kind, "cores": cores, "nproc": nproc, "affinity": share, "seconds": sorted(secs)[len(secs) // 2], "all": secs,
+               "frames": len(secs), "cmd": os.path.basename(cmd[0])}
         # the same program built for this host's vector units (-march=x86-64-v3, contraction off: same pixels)
         v3 = ref + "_v3"
         try:

@@ -281,6 +281,39 @@ int rtx_render_device_noalloc(rtx_scene *scene, const rtx_render_params *p, void
 int rtx_untile(const rtx_render_params *p, int32_t n_ranks, const void *d_gathered_u8, void *d_rgb_u8,
                int32_t bytes_per_pixel, void *stream);
 
+/* ---- one frame over several GPUs of a node ------------------------------------------- */
+
+/* The reference spreads a frame over eight host threads that own column strips of one canvas
+ * (src/main.cpp:34-52).  A scene group is that fan-out over GPUs: the scene replicated in the HBM
+ * of every listed device, the frame cut into tile_w x tile_h screen tiles dealt round-robin
+ * (tile k -> device k mod N), one RCCL all-gather of the devices' packed tile buffers over xGMI,
+ * and the first device of the list ("root") writing the row-major frame.  One process, one host
+ * thread, no Python; RCCL (librccl.so) is bound when the first group is created.
+ * devices == NULL or n_devices <= 0: the first n_devices devices, or all of the node's. */
+typedef struct rtx_scene_group rtx_scene_group;
+
+int rtx_scene_group_create(const rtx_scene_desc *desc, const int32_t *devices, int32_t n_devices, rtx_scene_group **out);
+int rtx_scene_group_create_from_host(const rtx_host_scene *hs, const int32_t *devices, int32_t n_devices,
+                                     rtx_scene_group **out);
+void rtx_scene_group_destroy(rtx_scene_group *group);
+int32_t rtx_scene_group_size(const rtx_scene_group *group);
+/* HIP ordinal and scene replica of member i (the replica stays owned by the group). */
+int32_t rtx_scene_group_device(const rtx_scene_group *group, int32_t i);
+rtx_scene *rtx_scene_group_scene(rtx_scene_group *group, int32_t i);
+
+/* One frame into a HOST buffer (3 bytes per pixel, row-major), rendered by all members; replaces
+ * the fan-out and join of src/main.cpp:45-52.  p->tile_rank, tile_count and layout are set by the
+ * call; hit ids and counters are not gathered (render one member's scene for those). */
+int rtx_render_sharded(rtx_scene_group *group, const rtx_render_params *p, uint8_t *rgb_out);
+
+/* The same frame left on the root device, asynchronously: the work is queued on frame slot `slot`
+ * (0..3, each with its own streams and buffers, so up to four frames overlap) and *d_rgb_u8
+ * receives the root-device pointer of that slot's frame, complete after rtx_scene_group_sync().
+ * A slot's next frame is ordered behind its previous one. */
+int rtx_render_sharded_device(rtx_scene_group *group, const rtx_render_params *p, int32_t slot, void **d_rgb_u8);
+/* Waits for frame slot `slot` on every member; negative = all slots. */
+int rtx_scene_group_sync(rtx_scene_group *group, int32_t slot);
+
 /* saveCanvas (src/main.cpp:96-116): binary P6, "P6\n<W> <H> 255\n" + rows. */
 int rtx_save_ppm(const char *path, int32_t width, int32_t height, const uint8_t *rgb);
 /* The same canvas as an 8-bit RGB PNG (uncompressed deflate blocks).  No counterpart in the

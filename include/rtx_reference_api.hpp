@@ -34,11 +34,19 @@ namespace rtx_reference_api_detail {
 struct Handles {
     rtx_host_scene *host = nullptr;
     rtx_scene *device = nullptr;
+    rtx_scene_group *group = nullptr;      /* more than one GPU: replicas on all of them instead of `device` */
     ~Handles() {
+        rtx_scene_group_destroy(group);
         rtx_scene_destroy(device);
         rtx_host_scene_free(host);
     }
 };
+/* GPUs a Scene loaded from now on is spread over (the reference's threadsSize, src/main.cpp:35, counts host
+ * threads); 1 = one GPU and no RCCL, 0 = every GPU of the node. */
+inline int &gpus() {
+    static int n = 1;
+    return n;
+}
 }  // namespace rtx_reference_api_detail
 
 /* include/scene.hpp:15-76: here a handle to the scene on the host and in HBM; copies share it (the reference
@@ -52,8 +60,13 @@ struct Scene {
         /* verbose: the "[ TRI ]" line of parseOBJ (scene.hpp:248); no tree on the host, it is built on the GPU */
         if (rtx_host_scene_load_obj_ex(path.c_str(), name, RTX_LOAD_VERBOSE | RTX_LOAD_NO_BVH, -1, &h->host) != RTX_OK)
             throw rtx_last_error();                                                            /* scene.hpp:216-218 */
-        if (rtx_scene_create_from_host(h->host, -1, &h->device) != RTX_OK) throw rtx_last_error();
-        const double s = rtx_scene_build_seconds(h->device);
+        const int n_gpus = rtx_reference_api_detail::gpus();
+        if (n_gpus == 1) {
+            if (rtx_scene_create_from_host(h->host, -1, &h->device) != RTX_OK) throw rtx_last_error();
+        } else {
+            if (rtx_scene_group_create_from_host(h->host, nullptr, n_gpus, &h->group) != RTX_OK) throw rtx_last_error();
+        }
+        const double s = rtx_scene_build_seconds(h->group ? rtx_scene_group_scene(h->group, 0) : h->device);
         printf("[ BVH ] %g seconds.\n", static_cast<double>(static_cast<long long>(s * 1000.0)) / 1000.0);   /* scene.hpp:49-51 */
         Scene scene;
         scene.handles = h;
@@ -81,12 +94,17 @@ inline void render(Scene scene, int xMin, int xMax) {
     p.x1 = xMax + CANVAS_WIDTH / 2;
     p.y0 = 0;
     p.y1 = CANVAS_HEIGHT;
+    auto frame_into = [&](uint8_t *rgb) {                /* on one GPU, or tiles over all GPUs of the group + RCCL gather */
+        const int rc = scene.handles->group ? rtx_render_sharded(scene.handles->group, &p, rgb)
+                                            : rtx_render(scene.handles->device, &p, rgb, nullptr, nullptr);
+        if (rc != RTX_OK) throw rtx_last_error();
+    };
     if (p.x0 == 0 && p.x1 == CANVAS_WIDTH) {            /* the whole frame: straight into the canvas */
-        if (rtx_render(scene.handles->device, &p, canvas().data(), nullptr, nullptr) != RTX_OK) throw rtx_last_error();
+        frame_into(canvas().data());
         return;
     }
     std::vector<uint8_t> frame(canvas().size());         /* a strip: rendered into a frame of its own, its columns kept */
-    if (rtx_render(scene.handles->device, &p, frame.data(), nullptr, nullptr) != RTX_OK) throw rtx_last_error();
+    frame_into(frame.data());
     for (int row = 0; row < CANVAS_HEIGHT; row++) {
         const size_t at = (static_cast<size_t>(row) * CANVAS_WIDTH + static_cast<size_t>(p.x0)) * 3;
         std::copy(frame.begin() + at, frame.begin() + at + static_cast<size_t>(p.x1 - p.x0) * 3, canvas().begin() + at);

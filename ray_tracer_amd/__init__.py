@@ -108,6 +108,8 @@ EXPORTS = (
     "rtx_host_scene_load_obj_ex", "rtx_host_scene_standin_ex",
     "rtx_bvh_build", "rtx_host_scene_rebuild_bvh", "rtx_scene_create_with_builder", "rtx_scene_build_seconds",
     "rtx_scene_bvh_nodes", "rtx_scene_bvh_depth", "rtx_render_device_noalloc",
+    "rtx_scene_group_create", "rtx_scene_group_create_from_host", "rtx_scene_group_destroy", "rtx_scene_group_size",
+    "rtx_scene_group_device", "rtx_scene_group_scene", "rtx_render_sharded", "rtx_render_sharded_device", "rtx_scene_group_sync",
 )
 
 _lib = None
@@ -165,6 +167,19 @@ def lib() -> C.CDLL:
     L.rtx_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, vp, vp, vp]
     L.rtx_render_device_timed.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, vp, vp, vp, vp]
     L.rtx_render_device_noalloc.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, vp, vp, vp]
+    L.rtx_scene_group_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_int32), C.c_int32, C.POINTER(vp)]
+    L.rtx_scene_group_create_from_host.argtypes = [vp, C.POINTER(C.c_int32), C.c_int32, C.POINTER(vp)]
+    L.rtx_scene_group_destroy.argtypes = [vp]
+    L.rtx_scene_group_destroy.restype = None
+    L.rtx_scene_group_size.argtypes = [vp]
+    L.rtx_scene_group_size.restype = C.c_int32
+    L.rtx_scene_group_device.argtypes = [vp, C.c_int32]
+    L.rtx_scene_group_device.restype = C.c_int32
+    L.rtx_scene_group_scene.argtypes = [vp, C.c_int32]
+    L.rtx_scene_group_scene.restype = vp
+    L.rtx_render_sharded.argtypes = [vp, C.POINTER(RenderParams), vp]
+    L.rtx_render_sharded_device.argtypes = [vp, C.POINTER(RenderParams), C.c_int32, C.POINTER(vp)]
+    L.rtx_scene_group_sync.argtypes = [vp, C.c_int32]
     L.rtx_untile.argtypes = [C.POINTER(RenderParams), C.c_int32, vp, vp, C.c_int32, vp]
     L.rtx_save_ppm.argtypes = [C.c_char_p, C.c_int32, C.c_int32, vp]
     L.rtx_save_png.argtypes = [C.c_char_p, C.c_int32, C.c_int32, vp]
@@ -442,6 +457,54 @@ class Scene:
     def close(self) -> None:
         if self._h:
             lib().rtx_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SceneGroup:
+    """A scene replicated on several GPUs of the node and rendered cooperatively from one process
+    (rtx_scene_group_*): screen tiles round-robin over the devices, one RCCL all-gather, frame on the first device."""
+
+    def __init__(self, host: HostScene, devices=None, n_devices: int = 0):
+        h = C.c_void_p()
+        if devices is not None:
+            arr = (C.c_int32 * len(devices))(*devices)
+            _check(lib().rtx_scene_group_create_from_host(host._h, arr, len(devices), C.byref(h)))
+        else:
+            _check(lib().rtx_scene_group_create_from_host(host._h, None, n_devices, C.byref(h)))
+        self._h = h
+
+    @property
+    def size(self) -> int:
+        return int(lib().rtx_scene_group_size(self._h))
+
+    def devices(self) -> list:
+        return [int(lib().rtx_scene_group_device(self._h, i)) for i in range(self.size)]
+
+    def render(self, width: int, height: int, **kw) -> np.ndarray:
+        """One frame through rtx_render_sharded(): (H, W, 3) uint8."""
+        p = make_params(width, height, **kw)
+        rgb = np.zeros((height, width, 3), dtype=np.uint8)
+        _check(lib().rtx_render_sharded(self._h, C.byref(p), rgb.ctypes.data))
+        return rgb
+
+    def submit(self, params: RenderParams, slot: int) -> int:
+        """Queues a frame on `slot`; returns the root-device pointer of the slot's frame (valid after sync())."""
+        ptr = C.c_void_p()
+        _check(lib().rtx_render_sharded_device(self._h, C.byref(params), slot, C.byref(ptr)))
+        return int(ptr.value or 0)
+
+    def sync(self, slot: int = -1) -> None:
+        _check(lib().rtx_scene_group_sync(self._h, slot))
+
+    def close(self) -> None:
+        if self._h:
+            lib().rtx_scene_group_destroy(self._h)
             self._h = None
 
     def __del__(self):

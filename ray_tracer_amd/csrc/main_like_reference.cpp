@@ -1,12 +1,15 @@
 // A driver with the shape of the reference's src/main.cpp:24-73, written against include/rtx_reference_api.hpp:
 // Scene::teapot(), render(scene, xMin, xMax) over eight column strips, three timed repeats printed in seconds with
 // three decimals, saveCanvas(), string literals thrown on failure and turned into exit code -1.  Run from a
-// directory that holds scenes/teapot.obj and out/, as the reference is.
+// directory that holds scenes/teapot.obj and out/, as the reference is.  `--gpus N` (N = 0: all) spreads every
+// frame over N GPUs of the node: the place of the reference's eight threads (src/main.cpp:34-52) is taken by
+// screen tiles dealt to the GPUs and one RCCL gather, all inside the library.
 #define CANVAS_WIDTH 1920
 #define CANVAS_HEIGHT 1920
 #include "rtx_reference_api.hpp"
 
 #include <chrono>
+#include <cstdlib>
 #include <iomanip>
 #include <iostream>
 #include <thread>
@@ -14,6 +17,8 @@
 int main(int argc, char **argv) {
     const bool one_call = argc > 1 && std::string(argv[1]) == "--whole-frame";   // one render() for the whole width
     const bool threaded = argc > 1 && std::string(argv[1]) == "--threads";       // the strips from eight threads at once, as the reference starts them
+    for (int a = 1; a + 1 < argc; a++)
+        if (std::string(argv[a]) == "--gpus") rtx_reference_api_detail::gpus() = std::atoi(argv[a + 1]);
     Scene scene;
     try {
         scene = Scene::teapot();

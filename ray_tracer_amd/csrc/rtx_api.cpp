@@ -277,6 +277,8 @@ uint64_t packed_tiles_per_rank(const rtx::DevRender &r) {
 extern "C" {
 
 const char *rtx_last_error(void) { return g_error.c_str(); }
+// for the library's other translation units (rtx_group.cpp): the calling thread's error text
+void rtx_set_last_error_(const char *message) { g_error = message ? message : ""; }
 const char *rtx_version(void) { return "rtx-mi355x 0.1 (gfx950)"; }
 
 // ------------------------------------------------------------------ host scenes

@@ -1,13 +1,16 @@
+"""Worker of tests/test_gpu_rccl_single_rank.py: the pipelined multi-GPU frame loop (render own tiles -> RCCL all-gather ->
+re-assembly, three frames in flight) with a process group of backend "nccl" (= RCCL) and ONE rank, which is all a one-GPU
+box can hold.  The process plays both ranks of a two-way tile split; the all-gather moves the packed buffer through RCCL."""
 import os, sys
-sys.path.insert(0, os.getcwd())
-os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 3000))
 import torch, torch.distributed as dist, ctypes as C, zlib
 import ray_tracer_amd as rt
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev,
                         pg_options=dist.ProcessGroupNCCL.Options(is_high_priority_stream=True))
-hs = rt.HostScene.load_obj("tests/golden/teapot.obj", "teapot", no_bvh=True)
+hs = rt.HostScene.load_obj(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "teapot.obj"), "teapot", no_bvh=True)
 scene = rt.Scene(hs)
 W, H = 1920, 1080
 world = 1

@@ -65,6 +65,21 @@ def test_render_without_a_gpu_is_an_error_not_a_fallback(teapot_obj):
         rt.build_bvh(host.arrays()["vertices"], builder=rt.BUILDER_DEVICE)
 
 
+def test_scene_group_without_a_gpu_is_an_error(teapot_obj):
+    """The multi-GPU entry points fail with a status and a message where there is no GPU (or no RCCL): nothing crashes."""
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this machine has a GPU")
+    host = rt.HostScene.load_obj(teapot_obj, "teapot")
+    with pytest.raises(rt.RtxError) as e:
+        rt.SceneGroup(host, n_devices=0)
+    assert e.value.code in (-3, -4) and str(e.value)
+    lib = rt.lib()
+    assert lib.rtx_scene_group_size(None) == 0 and lib.rtx_scene_group_device(None, 0) == -1
+    lib.rtx_scene_group_destroy(None)
+
+
 def test_header_is_plain_c(tmp_path):
     """include/rtx.h is what a C, cgo or FFI binding includes: it must compile as C99 on its own."""
     import subprocess
