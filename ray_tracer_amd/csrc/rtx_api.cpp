@@ -48,6 +48,16 @@ struct rtx_scene {
     void *d_out_rgb = nullptr, *d_out_hit = nullptr, *d_out_stats = nullptr, *h_out_rgb = nullptr, *h_out_hit = nullptr;
     uint64_t out_rgb_bytes = 0, out_hit_bytes = 0;
     hipEvent_t out_e0 = nullptr, out_e1 = nullptr;
+    // rtx_render_begin() / rtx_render_end(): frames on their way to host memory, each slot with its own stream,
+    // device buffers and pinned host buffers
+    struct HostSlot {
+        hipStream_t stream = nullptr;
+        void *d_rgb = nullptr, *h_rgb = nullptr, *d_hit = nullptr, *h_hit = nullptr;
+        uint64_t rgb_bytes = 0, hit_bytes = 0, pixels = 0;
+        bool want_hit = false, busy = false;
+    };
+    static constexpr int kHostSlots = 4;
+    HostSlot host_slots[kHostSlots];
     uint64_t bytes = 0;
     uint64_t n_triangles = 0;
     double build_seconds = 0.0;   // BVH build inside rtx_scene_create*, 0 when the caller brought the tree
@@ -312,7 +322,7 @@ static int host_scene_standin_ex_impl(const char *preset, uint64_t n_triangles, 
     std::vector<double> verts;
     std::vector<uint32_t> faces;
     std::string err;
-    if (int rc = rtx::generate_standin(preset, n_triangles, seed, &verts, &faces, &err)) return fail(rc, err);
+    if (int rc = rtx::generate_standin(preset, n_triangles, seed, (flags & RTX_STANDIN_KNOT) ? 1 : 0, &verts, &faces, &err)) return fail(rc, err);
     if (obj_path_out)
         if (int rc = rtx::write_obj(obj_path_out, verts, faces, &err)) return fail(rc, err);
     if (!out) return RTX_OK;
@@ -664,6 +674,13 @@ void rtx_scene_destroy(rtx_scene *sc) {
     (void)hipFree(sc->d_out_stats);
     if (sc->h_out_rgb) (void)hipHostFree(sc->h_out_rgb);
     if (sc->h_out_hit) (void)hipHostFree(sc->h_out_hit);
+    for (rtx_scene::HostSlot &h : sc->host_slots) {
+        if (h.stream) { (void)hipStreamSynchronize(h.stream); (void)hipStreamDestroy(h.stream); }
+        (void)hipFree(h.d_rgb);
+        (void)hipFree(h.d_hit);
+        if (h.h_rgb) (void)hipHostFree(h.h_rgb);
+        if (h.h_hit) (void)hipHostFree(h.h_hit);
+    }
     if (sc->out_e0) (void)hipEventDestroy(sc->out_e0);
     if (sc->out_e1) (void)hipEventDestroy(sc->out_e1);
     delete sc;
@@ -679,7 +696,7 @@ void rtx_render_params_default(rtx_render_params *p, int32_t width, int32_t heig
     p->height = height;
     p->depth = 3;              // src/main.cpp:83
     p->spp = 1;
-    p->traversal = RTX_TRAVERSAL_REFERENCE;
+    p->traversal = RTX_TRAVERSAL_PRUNED;      // the same frame as RTX_TRAVERSAL_REFERENCE, bit for bit, in less time
     p->tile_w = 32;
     p->tile_h = 32;
     p->tile_count = 1;
@@ -924,6 +941,56 @@ static int render_impl(rtx_scene *sc, const rtx_render_params *p, uint8_t *rgb_o
     return RTX_OK;
 }
 
+// rtx_render() in two halves, so that a frame's trip to host memory overlaps the next frame's render.
+static int render_begin_impl(rtx_scene *sc, const rtx_render_params *p, int32_t slot, int32_t want_hit_ids) {
+    if (!sc) return fail(RTX_ERR_INVALID, "scene is NULL");
+    if (slot < 0 || slot >= rtx_scene::kHostSlots) return fail(RTX_ERR_INVALID, "frame slot must be 0..3");
+    ResolvedParams rp;
+    if (int rc = resolve_params(p, &rp)) return rc;
+    if (want_hit_ids && rp.r.layout == RTX_LAYOUT_PACKED_TILES) return fail(RTX_ERR_INVALID, "hit ids / t are only written in row-major layout");
+    const uint64_t px = rtx_output_pixels(p);
+    std::lock_guard<std::mutex> hold(sc->lock);
+    rtx_scene::HostSlot &h = sc->host_slots[slot];
+    if (h.busy) return fail(RTX_ERR_INVALID, "frame slot still holds a frame: call rtx_render_end() first");
+    DeviceGuard guard(sc->device);
+    if (!guard.ok) return fail(RTX_ERR_DEVICE, "cannot select the scene's device");
+    if (!h.stream) HIP_TRY(hipStreamCreateWithFlags(&h.stream, hipStreamNonBlocking));
+    h.pixels = px;
+    h.want_hit = want_hit_ids != 0;
+    h.busy = true;
+    if (px == 0) return RTX_OK;
+    HIP_TRY(grow_pair(&h.d_rgb, &h.h_rgb, &h.rgb_bytes, px * 3));
+    if (h.want_hit) HIP_TRY(grow_pair(&h.d_hit, &h.h_hit, &h.hit_bytes, px * 4));
+    // pixels outside the window (and the padding of packed tiles) read 0 / -1
+    HIP_TRY(hipMemsetAsync(h.d_rgb, 0, px * 3, h.stream));
+    if (h.want_hit) HIP_TRY(hipMemsetAsync(h.d_hit, 0xff, px * 4, h.stream));
+    if (int rc = rtx_render_device(sc, p, h.d_rgb, h.want_hit ? h.d_hit : nullptr, nullptr, nullptr, nullptr, h.stream)) { h.busy = false; return rc; }
+    HIP_TRY(hipMemcpyAsync(h.h_rgb, h.d_rgb, px * 3, hipMemcpyDeviceToHost, h.stream));
+    if (h.want_hit) HIP_TRY(hipMemcpyAsync(h.h_hit, h.d_hit, px * 4, hipMemcpyDeviceToHost, h.stream));
+    return RTX_OK;
+}
+
+static int render_end_impl(rtx_scene *sc, int32_t slot, uint8_t *rgb_out, int32_t *hit_id_out) {
+    if (!sc) return fail(RTX_ERR_INVALID, "scene is NULL");
+    if (slot < 0 || slot >= rtx_scene::kHostSlots) return fail(RTX_ERR_INVALID, "frame slot must be 0..3");
+    rtx_scene::HostSlot &h = sc->host_slots[slot];
+    {
+        std::lock_guard<std::mutex> hold(sc->lock);
+        if (!h.busy) return fail(RTX_ERR_INVALID, "frame slot holds no frame: call rtx_render_begin() first");
+        if (hit_id_out && !h.want_hit) return fail(RTX_ERR_INVALID, "hit ids were not asked for in rtx_render_begin()");
+    }
+    if (h.pixels) {
+        DeviceGuard guard(sc->device);
+        if (!guard.ok) return fail(RTX_ERR_DEVICE, "cannot select the scene's device");
+        HIP_TRY(hipStreamSynchronize(h.stream));
+        if (rgb_out) rtx::parallel_copy(rgb_out, h.h_rgb, h.pixels * 3);
+        if (hit_id_out) rtx::parallel_copy(hit_id_out, h.h_hit, h.pixels * 4);
+    }
+    std::lock_guard<std::mutex> hold(sc->lock);
+    h.busy = false;
+    return RTX_OK;
+}
+
 int rtx_untile(const rtx_render_params *p, int32_t n_ranks, const void *d_gathered, void *d_out, int32_t bpp, void *stream) {
     ResolvedParams rp;
     if (int rc = resolve_params(p, &rp)) return rc;
@@ -1150,6 +1217,14 @@ int rtx_render_device_noalloc(rtx_scene *sc, const rtx_render_params *p, void *d
 
 int rtx_render(rtx_scene *sc, const rtx_render_params *p, uint8_t *rgb_out, int32_t *hit_id_out, rtx_stats *stats) {
     return guarded([&]() -> int { return render_impl(sc, p, rgb_out, hit_id_out, stats); });
+}
+
+int rtx_render_begin(rtx_scene *sc, const rtx_render_params *p, int32_t slot, int32_t want_hit_ids) {
+    return guarded([&]() -> int { return render_begin_impl(sc, p, slot, want_hit_ids); });
+}
+
+int rtx_render_end(rtx_scene *sc, int32_t slot, uint8_t *rgb_out, int32_t *hit_id_out) {
+    return guarded([&]() -> int { return render_end_impl(sc, slot, rgb_out, hit_id_out); });
 }
 
 int rtx_selftest_pow(uint64_t n, uint64_t seed, uint64_t *differing, uint64_t *max_ulps) {

@@ -10,13 +10,11 @@
 #include <string>
 #include <vector>
 
-#include <hip/hip_runtime_api.h>
-
 #include "rtx.h"
 
 int main(int argc, char **argv) {
-    std::string scene = "teapot", obj, out = "out/canvas.ppm", mode = "reference", builder = "device";
-    bool tolerant = false, overlap = false;
+    std::string scene = "teapot", obj, out = "out/canvas.ppm", mode = "pruned", builder = "device";
+    bool tolerant = false, overlap = false, knot = false;
     int width = 1920, height = 1920, depth = 3, spp = 1, repeats = 3, device = -1;
     unsigned long long standin = 0;
     for (int i = 1; i < argc; i++) {
@@ -35,10 +33,11 @@ int main(int argc, char **argv) {
         else if (a == "--standin") standin = strtoull(val(), nullptr, 10);
         else if (a == "--builder") builder = val();
         else if (a == "--tolerant") tolerant = true;
+        else if (a == "--knot") knot = true;
         else if (a == "--overlap") overlap = true;
         else {
             fprintf(stderr,
-                    "usage: %s [--scene teapot|bunny|erato|dragon|aurelius] [--obj FILE | --standin NTRIS] [--width W] "
+                    "usage: %s [--scene teapot|bunny|erato|dragon|aurelius] [--obj FILE | --standin NTRIS [--knot]] [--width W] "
                     "[--height H] [--depth D] [--spp N] [--mode reference|pruned] [--builder device|host] [--tolerant] [--overlap] [--repeats N] "
                     "[--device K] [--out FILE]\n",
                     argv[0]);
@@ -49,7 +48,7 @@ int main(int argc, char **argv) {
 
     // With the device builder the host scene carries no tree: it is built, and stays, on the GPU.
     const bool on_device = builder != "host";
-    const uint32_t flags = RTX_LOAD_VERBOSE | (on_device ? RTX_LOAD_NO_BVH : 0) | (tolerant ? RTX_LOAD_TOLERANT : 0);
+    const uint32_t flags = RTX_LOAD_VERBOSE | (on_device ? RTX_LOAD_NO_BVH : 0) | (tolerant ? RTX_LOAD_TOLERANT : 0) | (knot ? RTX_STANDIN_KNOT : 0);
     rtx_host_scene *hs = nullptr;
     int rc = standin ? rtx_host_scene_standin_ex(scene.c_str(), standin, 0, nullptr, flags, device, &hs)
                      : rtx_host_scene_load_obj_ex(obj.c_str(), scene.c_str(), flags, device, &hs);
@@ -66,6 +65,8 @@ int main(int argc, char **argv) {
     p.depth = depth;
     p.spp = spp;
     p.traversal = mode == "pruned" ? RTX_TRAVERSAL_PRUNED : RTX_TRAVERSAL_REFERENCE;
+    // the kernel keeps a pixel's column and row in 16 bits each; anything else ends the way the reference's errors do
+    if (width < 1 || height < 1 || width > 65535 || height > 65535 || repeats < 0) { fprintf(stderr, "canvas size must be 1..65535 in each dimension\n"); return -1; }
     std::vector<uint8_t> rgb((size_t)width * height * 3);
     auto save = [&](const uint8_t *pixels) {
         const bool png = out.size() > 4 && out.compare(out.size() - 4, 4, ".png") == 0;
@@ -82,43 +83,20 @@ int main(int argc, char **argv) {
         printf("\n");
         if (save(rgb.data()) != RTX_OK) { fprintf(stderr, "%s", rtx_last_error()); return -1; }
     } else {
-        // The repeat loop with the frames overlapped: frame n renders on stream n % 2 into a device
-        // buffer and is copied to pinned host memory on the same stream, so its copy (and the end
-        // of its kernel, when lanes run dry) overlaps the next frame's render.  The times printed
-        // are the intervals between finished frames.
-        hipStream_t streams[2];
-        void *d_buf[2] = {nullptr, nullptr}, *h_buf[2] = {nullptr, nullptr};
-        hipEvent_t done[2];
-        bool hip_ok = true;
-        for (int k = 0; k < 2; k++) {
-            hip_ok = hip_ok && hipStreamCreateWithFlags(&streams[k], hipStreamNonBlocking) == hipSuccess &&
-                     hipMalloc(&d_buf[k], rgb.size()) == hipSuccess && hipHostMalloc(&h_buf[k], rgb.size(), hipHostMallocDefault) == hipSuccess &&
-                     hipEventCreate(&done[k]) == hipSuccess;
-        }
-        if (!hip_ok) { fprintf(stderr, "cannot set up the overlapped frame loop\n"); return -1; }
+        // The repeat loop with the frames overlapped (rtx_render_begin / rtx_render_end): frame n + 1 is queued before
+        // frame n is waited for, so a frame's copy to host memory (and the end of its kernel, when lanes run dry)
+        // overlaps the next frame's render.  The times printed are the intervals between delivered frames.
         auto last = std::chrono::high_resolution_clock::now();
-        auto finish = [&](int k) {
-            if (hipEventSynchronize(done[k]) != hipSuccess) return false;
-            auto now = std::chrono::high_resolution_clock::now();
+        if (repeats > 0 && rtx_render_begin(sc, &p, 0, 0) != RTX_OK) { fprintf(stderr, "%s\n", rtx_last_error()); return -1; }
+        for (int n = 0; n < repeats; n++) {
+            if (n + 1 < repeats && rtx_render_begin(sc, &p, (n + 1) & 1, 0) != RTX_OK) { fprintf(stderr, "%s\n", rtx_last_error()); return -1; }
+            if (rtx_render_end(sc, n & 1, rgb.data(), nullptr) != RTX_OK) { fprintf(stderr, "%s\n", rtx_last_error()); return -1; }
+            const auto now = std::chrono::high_resolution_clock::now();
             printf("%.4f ", std::chrono::duration<double>(now - last).count());
             last = now;
-            return true;
-        };
-        for (int n = 0; n < repeats; n++) {
-            const int k = n & 1;
-            if (n >= 2 && !finish(k)) { fprintf(stderr, "frame did not finish\n"); return -1; }
-            if (rtx_render_device(sc, &p, d_buf[k], nullptr, nullptr, nullptr, nullptr, streams[k]) != RTX_OK) { fprintf(stderr, "%s\n", rtx_last_error()); return -1; }
-            if (hipMemcpyAsync(h_buf[k], d_buf[k], rgb.size(), hipMemcpyDeviceToHost, streams[k]) != hipSuccess ||
-                hipEventRecord(done[k], streams[k]) != hipSuccess) { fprintf(stderr, "copy of the frame failed\n"); return -1; }
         }
-        for (int n = repeats > 2 ? repeats - 2 : 0; n < repeats; n++)
-            if (!finish(n & 1)) { fprintf(stderr, "frame did not finish\n"); return -1; }
         printf("\n");
-        const int rc_save = repeats > 0 ? save(static_cast<const uint8_t *>(h_buf[(repeats - 1) & 1])) : RTX_OK;
-        for (int k = 0; k < 2; k++) {
-            (void)hipEventDestroy(done[k]); (void)hipHostFree(h_buf[k]); (void)hipFree(d_buf[k]); (void)hipStreamDestroy(streams[k]);
-        }
-        if (rc_save != RTX_OK) { fprintf(stderr, "%s", rtx_last_error()); return -1; }
+        if (repeats > 0 && save(rgb.data()) != RTX_OK) { fprintf(stderr, "%s", rtx_last_error()); return -1; }
     }
     rtx_scene_destroy(sc);
     rtx_host_scene_free(hs);

@@ -56,3 +56,47 @@ def test_sharded_renderer_single_rank_with_frames_in_flight():
     for f in r.frames:
         assert np.array_equal(f.cpu().numpy().reshape(200, 320, 3), want)
     assert np.array_equal(r.render().cpu().numpy().reshape(200, 320, 3), want)
+
+
+def test_render_begin_end_loop_delivers_the_same_frames():
+    """rtx_render_begin / rtx_render_end: frame n + 1 queued before frame n is collected; every frame equals rtx_render's."""
+    hs = rt.HostScene.load_obj(os.path.join(HERE, "golden", "teapot.obj"), "teapot", no_bvh=True)
+    scene = rt.Scene(hs)
+    W, H = 480, 272
+    want = scene.render(W, H, traversal=rt.TRAVERSAL_PRUNED)
+    p = rt.make_params(W, H, traversal=rt.TRAVERSAL_PRUNED)
+    frames = 7
+    scene.render_begin(p, 0, want_hit=True)
+    for n in range(frames):
+        if n + 1 < frames:
+            scene.render_begin(p, (n + 1) % 2, want_hit=True)
+        rgb = np.zeros((H, W, 3), dtype=np.uint8)
+        hit = np.zeros((H, W), dtype=np.int32)
+        scene.render_end(n % 2, rgb, hit)
+        assert np.array_equal(rgb, want.rgb) and np.array_equal(hit, want.hit), n
+    # a window: pixels outside it read 0 / -1, as with rtx_render
+    kw = dict(traversal=rt.TRAVERSAL_PRUNED, window=(40, 400, 16, 200))
+    want = scene.render(W, H, **kw)
+    scene.render_begin(rt.make_params(W, H, **kw), 3, want_hit=True)
+    rgb = np.full((H, W, 3), 9, dtype=np.uint8)
+    hit = np.zeros((H, W), dtype=np.int32)
+    scene.render_end(3, rgb, hit)
+    assert np.array_equal(rgb, want.rgb) and np.array_equal(hit, want.hit)
+    # slots hold one frame at a time
+    with pytest.raises(rt.RtxError):
+        scene.render_end(1, rgb)
+    scene.render_begin(p, 1)
+    with pytest.raises(rt.RtxError):
+        scene.render_begin(p, 1)
+    with pytest.raises(rt.RtxError):
+        scene.render_end(1, rgb, hit)             # ids were not asked for
+    scene.render_end(1, rgb)
+    with pytest.raises(rt.RtxError):
+        scene.render_begin(p, 4)
+
+
+def test_default_params_select_the_pruned_traversal():
+    import ctypes as C
+    p = rt.RenderParams()
+    rt.lib().rtx_render_params_default(C.byref(p), 64, 48)
+    assert (p.traversal, p.depth, p.spp, p.tile_w, p.tile_h) == (rt.TRAVERSAL_PRUNED, 3, 1, 32, 32)
