@@ -110,6 +110,9 @@ def main():
                          "overlaps the start of the next one; 1 = every frame waits for the previous one; 4 = one stream "
                          "per hardware queue of the process (the default); from 8 ranks up the default is 8 and the process asks for 8 "
                          "hardware queues: a rank's share of a frame is short then, so more of them overlap")
+    ap.add_argument("--family", choices=["blob", "knot"], default="blob",
+                    help="stand-in mesh family: blob = a bumpy star-shaped surface in a box around z = 0 (the headline of every "
+                         "round); knot = a knotted tube (concave, self-occluding, self-reflecting) in a box that fills the view")
     ap.add_argument("--obj", default=None, help="real .obj for the scene (default: the seeded stand-in mesh)")
     ap.add_argument("--tolerant", action="store_true",
                     help="read --obj with the general loader (vt/vn index groups, negative indices, comments) instead of the "
@@ -189,7 +192,7 @@ def main():
         want_obj = rank == 0 and not args.no_cpu_baseline and world == 1
         if want_obj:
             os.makedirs(obj_dir, exist_ok=True)
-        host = rt.HostScene.standin(args.scene, seed=0, obj_path_out=obj_path if want_obj else None, no_bvh=True)
+        host = rt.HostScene.standin(args.scene, seed=0, obj_path_out=obj_path if want_obj else None, no_bvh=True, family=args.family)
         data = "synthetic"
     load_s = time.time() - t0
     t0 = time.time()
@@ -302,7 +305,8 @@ def main():
     # 4 cycles, so a launch's wave-level VALU instructions (committed counter pass of this very frame) x 4 cycles over
     # all SIMDs is the least time its instruction stream needs.  achieved/peak are in lane-operations per second
     # (peak = SIMDs x 16 lanes x clock; the 78.6 TFLOP/s FP64 vector figure is this peak with every slot an FMA).
-    counters = profiled_counters(f"{args.scene}_{W}x{H}_{args.mode}") if world == 1 and not args.obj and args.spp == 1 else None
+    scene_key = args.scene if args.family == "blob" else f"{args.scene}_{args.family}"
+    counters = profiled_counters(f"{scene_key}_{W}x{H}_{args.mode}") if world == 1 and not args.obj and args.spp == 1 else None
     peak_laneops = simds * 16 * CLOCK_GHZ * 1e9
     own_bytes = cen_own["node_visits"] * 64 + cen_own["triangle_tests"] * 112          # what the timed kernel itself requests
     launch_alg_bytes = alg_bytes_frame / world         # this rank's launch covers 1/world of the tiles
@@ -363,7 +367,7 @@ def main():
         "dtype": "f64",
         "data": data,
         "config": {
-            "workload": f"{args.scene} ({host.n_triangles} triangles, {'real' if args.obj else 'stand-in'} mesh) "
+            "workload": f"{args.scene} ({host.n_triangles} triangles, {'real' if args.obj else 'stand-in, ' + args.family + ' family'} mesh) "
                         f"{W}x{H}, depth {args.depth}, {args.spp} spp, traversal={args.mode}",
             "parallelism": f"screen tiles {args.tile}x{args.tile} interleaved over {world} GPU(s)"
                            + ((", RCCL all-gather of packed tiles" if args.backend == "nccl" else ", gloo all-gather through host memory (rehearsal)") if packed else ""),

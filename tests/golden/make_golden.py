@@ -14,7 +14,8 @@ reference's own headers compiled from /root/reference, see oracle/ref_harness.cp
                                        factories only ever turn the camera by 0.1 degrees)
 
 `make_golden.py --turned-only` regenerates just the turned-camera fixtures and keeps the rest of golden.json;
-`--full-size-only` adds the hashes of the two benchmarked 3840x2160 frames as the reference renders them (minutes).
+`--full-size-only` adds the hashes of the two benchmarked 3840x2160 frames as the reference renders them (minutes);
+`--knot-only` adds the fixtures of the knotted-tube stand-in family (small raw case, small and full-size hashes).
 """
 import hashlib
 import json
@@ -105,6 +106,33 @@ def main():
                 g[key]["obj_md5"] = hashlib.md5(open(obj, "rb").read()).hexdigest()
                 shutil.rmtree(root)
                 print(key, g[key]["hit_fnv"], flush=True)
+                with open(path, "w") as f:
+                    json.dump(g, f, indent=1, sort_keys=True)
+        return
+    if "--knot-only" in sys.argv:
+        # the second stand-in family (a knotted tube: concave, self-occluding) as the reference renders it: a small
+        # case with raw arrays, every scene at a small size and BASELINE's frames at their full sizes (hashes)
+        path = os.path.join(HERE, "golden.json")
+        g = json.load(open(path))
+        cases = [("bunny", 20010, 7, 192, 108, True)]
+        for scene, ntri, W, H in FULL_SIZE:
+            cases += [(scene, ntri, 0, 480, 270, False), (scene, ntri, 0, W, H, False)]
+        with tempfile.TemporaryDirectory() as tmp:
+            for scene, ntri, seed, W, H, keep_raw in cases:
+                key = f"knot_{scene}_{ntri}_seed{seed}_{W}x{H}"
+                if key in g and "--force" not in sys.argv:
+                    continue
+                root = os.path.join(tmp, f"{scene}{ntri}")
+                os.makedirs(os.path.join(root, "scenes"))
+                obj = os.path.join(root, "scenes", f"{scene}.obj")
+                rt.HostScene.standin(scene, ntri, seed=seed, obj_path_out=obj, no_bvh=True, family="knot").close()
+                p = os.path.join(tmp, key)
+                g[key] = run_ref(REF_BVH, scene, root, W, H, 3, p if keep_raw else "-")
+                g[key]["obj_md5"] = hashlib.md5(open(obj, "rb").read()).hexdigest()
+                if keep_raw:
+                    np.savez_compressed(os.path.join(HERE, f"knot_{scene}{ntri}_{W}x{H}.npz"), **raw(p, W, H))
+                shutil.rmtree(root)
+                print(key, g[key]["hit_fnv"], g[key].get("rays"), flush=True)
                 with open(path, "w") as f:
                     json.dump(g, f, indent=1, sort_keys=True)
         return

@@ -83,6 +83,36 @@ def test_benchmarked_frames_equal_the_reference_render(scene, ntri, W, H, golden
     dev.close()
 
 
+FULL = [("bunny", 144056, 1920, 1080), ("erato", 412508, 3840, 2160), ("dragon", 871316, 3840, 2160), ("aurelius", 1704768, 3840, 2160)]
+
+
+@pytest.mark.parametrize("scene,ntri,W,H", FULL)
+def test_knot_family_equals_the_reference_render(scene, ntri, W, H, golden):
+    """The second stand-in family (a knotted tube: concave, self-occluding, box filling the view) as the reference renders
+    the .obj this repository's generator wrote: a small frame and BASELINE's frame at its full size -- ids, t, unclamped
+    and 8-bit RGB of every pixel, both traversal modes, tree built on the device."""
+    dev = rt.Scene(rt.HostScene.standin(scene, ntri, seed=0, no_bvh=True, family="knot"))
+    for (w, h) in ((480, 270), (W, H)):
+        want = golden[f"knot_{scene}_{ntri}_seed0_{w}x{h}"]
+        assert dev.bvh_nodes == int(want["nodes_used"])
+        for mode in (rt.TRAVERSAL_PRUNED, rt.TRAVERSAL_REFERENCE):
+            _check(_render_all(dev, w, h, mode), want)
+    dev.close()
+
+
+@pytest.mark.parametrize("family,prefix", [("blob", "standin"), ("knot", "knot")])
+@pytest.mark.parametrize("scene,ntri,W,H", FULL)
+def test_device_built_tree_has_the_references_hashes(scene, ntri, W, H, family, prefix, golden):
+    """BVH::nodes and BVH::indices as the device builder leaves them, hashed against what the reference's own constructor
+    built from the same .obj (no host builder in between)."""
+    want = golden[f"{prefix}_{scene}_{ntri}_seed0_{W}x{H}"]
+    host = rt.HostScene.standin(scene, ntri, seed=0, no_bvh=True, family=family)
+    tree = rt.build_bvh(host.arrays()["vertices"], builder=rt.BUILDER_DEVICE)
+    assert len(tree["nodes"]) == int(want["nodes_used"])
+    assert fnv1a(tree["nodes"]) == want["nodes_fnv"]
+    assert fnv1a(tree["indices"]) == want["indices_fnv"]
+
+
 def test_full_size_modes_agree_and_census_is_canonical():
     """BASELINE's 4K dragon frame: too slow for the CPU oracle in a test, so it is checked through
     properties: both traversal modes give identical ids / RGB, every tile partition re-assembles to

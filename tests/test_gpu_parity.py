@@ -120,6 +120,22 @@ def test_supersampling_matches_oracle(teapot):
     assert np.array_equal(one.hit, got.hit)
 
 
+def test_aurelius_sixteen_samples_match_oracle(tmp_path):
+    """BASELINE's last configuration at a size the oracle renders in seconds: the aurelius stand-in (1.7 M triangles),
+    16 jittered samples per pixel, both families' worth of geometry through the same sampler -- ids and 8-bit RGB."""
+    obj = str(tmp_path / "aurelius.obj")
+    host = rt.HostScene.standin("aurelius", seed=0, obj_path_out=obj, no_bvh=True)
+    ora = OracleScene.load_obj(obj, "aurelius")
+    dev = rt.Scene(host)
+    W, H = 240, 136
+    want = ora.render(W, H, depth=3, spp=16, seed=0, threads=16)
+    for mode in (rt.TRAVERSAL_PRUNED, rt.TRAVERSAL_REFERENCE):
+        got = dev.render(W, H, depth=3, spp=16, seed=0, traversal=mode)
+        assert np.array_equal(got.hit, want["hit"])
+        assert np.array_equal(got.rgb, want["rgb_u8"])
+    dev.close()
+
+
 def test_window_and_odd_sizes(teapot):
     _, dev, ora = teapot
     W, H = 101, 67

@@ -98,6 +98,28 @@ def test_standin_raw_arrays_from_reference(golden, golden_dir, tmp_path):
     assert got["t"].tobytes() == arr["t"].tobytes()
 
 
+def test_knot_standin_raw_arrays_from_reference(golden, golden_dir, tmp_path):
+    """The knotted-tube stand-in family: the .obj the generator writes has the recorded md5, and the oracle's tree, ids,
+    colours and t equal what the reference produced from that file."""
+    import ray_tracer_amd as rt
+
+    obj = str(tmp_path / "bunny.obj")
+    rt.HostScene.standin("bunny", 20010, seed=7, obj_path_out=obj, family="knot").close()
+    want = golden["knot_bunny_20010_seed7_192x108"]
+    assert hashlib.md5(open(obj, "rb").read()).hexdigest() == want["obj_md5"]
+    s = OracleScene.load_obj(obj, "bunny")
+    assert fnv1a(s.nodes()) == want["nodes_fnv"] and fnv1a(s.indices()) == want["indices_fnv"]
+    arr = np.load(os.path.join(golden_dir, "knot_bunny20010_192x108.npz"))
+    got = s.render(192, 108, depth=3, want_t=True)
+    assert np.array_equal(got["hit"], arr["hit"]) and np.array_equal(got["rgb_i32"], arr["rgb_i32"])
+    assert got["t"].tobytes() == arr["t"].tobytes()
+    # nearly every primary ray ends on the model or on a wall of the box (the camera is turned by 0.1 degrees, so a
+    # sliver of the view passes the box's edge), and most reflected rays find geometry again
+    c = got["census"].as_dict() if hasattr(got["census"], "as_dict") else got["census"]
+    assert (arr["hit"] >= 0).mean() > 0.99
+    assert c["closest_hits"] - c["primary_rays"] > 0.5 * c["reflection_rays"]
+
+
 @pytest.mark.parametrize("k", [0, 1, 2, 3])
 def test_turned_cameras(teapot, golden, golden_dir, k):
     """All three rotation angles at once, quarter and half turns: pins cos/sin of the camera rotation the way
