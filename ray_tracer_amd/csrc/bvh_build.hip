@@ -34,6 +34,7 @@
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -546,7 +547,7 @@ struct Prefix {
 // Children of every node that splits (bvh.hpp:141-158); a partition that leaves one side
 // empty makes the node a leaf, but its permutation is still applied (bvh.hpp:139-141).
 __global__ void split_kernel(Nodes nd, Prefix pre, const uint8_t *__restrict__ flag, uint32_t level_begin, uint32_t level_end,
-                             Counters *__restrict__ counters, uint2 *__restrict__ small_list, uint32_t level) {
+                             Counters *__restrict__ counters, uint2 *__restrict__ small_list, uint32_t level, uint32_t level_cap) {
     const uint32_t t = level_begin + blockIdx.x * kBlock + threadIdx.x;
     if (t >= level_end || nd.count[t] <= kSmall || nd.axis[t] < 0) return;
     const uint32_t f0 = nd.first[t], m = nd.count[t];
@@ -558,6 +559,9 @@ __global__ void split_kernel(Nodes nd, Prefix pre, const uint8_t *__restrict__ f
     nd.kstar[t] = ks;
     if (nl == 0 || nl == m) return;
     const uint32_t c = atomicAdd(&counters->next_id, 2u);
+    // the per-level-node arrays hold `level_cap` records: past them nothing is written, the node stays without
+    // children and the host, which sees next_id beyond the bound after this level, starts over with larger arrays
+    if (c + 1 >= level_cap) return;
     nd.child[t] = c;
     init_node(nd, c, f0, nl, t, ((nd.link[t] >> 1) + 1) << 1);
     init_node(nd, c + 1, f0 + nl, m - nl, t, 1u);
@@ -1076,13 +1080,28 @@ struct DeviceBvh::Impl {
 DeviceBvh::DeviceBvh() = default;
 DeviceBvh::~DeviceBvh() { delete impl; }
 
+// One attempt with room for `top_cap` nodes in the level passes (nodes of more than kSmall triangles and their
+// children).  *overflow: the mesh needs more of them; nothing was written out of bounds.
+static int build_resident_attempt(const double *vertices, uint32_t n, uint32_t top_cap, DeviceBvh *out, std::string *err, bool *overflow);
+
 int build_bvh_resident(const double *vertices, uint64_t n64, DeviceBvh *out, std::string *err) {
     if (n64 == 0) { *err = "cannot build a BVH over zero triangles"; return RTX_ERR_INVALID; }
     if (n64 >= (1ull << 28)) { *err = "more than 2^28 triangles"; return RTX_ERR_UNSUPPORTED; }
     const uint32_t n = (uint32_t)n64;
-    // Nodes of the level passes: those with more than kSmall triangles (their leaves have
-    // disjoint ranges, so fewer than 2n/kSmall of them) and their small children.
-    const uint32_t top_cap = n / 8 + 1024;
+    // A node of the level passes has more than kSmall triangles or is the child of one.  Meshes as scanners and
+    // modelling tools produce them stay far below n / 8 such nodes; the true bound is 2n (a chain of splits that each
+    // peel one triangle off a large node), and a mesh that gets past the first estimate is built again with that.
+    bool overflow = false;
+    uint32_t estimate = n / 8 + 1024;
+    if (const char *v = getenv("RTX_BVH_LEVEL_NODES")) estimate = (uint32_t)std::max(4, atoi(v));   // tests: force the second attempt
+    int rc = build_resident_attempt(vertices, n, estimate, out, err, &overflow);
+    if (overflow) rc = build_resident_attempt(vertices, n, 2 * n + 2, out, err, &overflow);
+    if (overflow) { *err = "BVH build: more level nodes than their bound"; return RTX_ERR_DEVICE; }
+    return rc;
+}
+
+static int build_resident_attempt(const double *vertices, uint32_t n, uint32_t top_cap, DeviceBvh *out, std::string *err, bool *overflow) {
+    *overflow = false;
     const uint32_t cap = top_cap + 2 * n;            // + 2m-2 reserved ids per small root
     const uint32_t chunks = blocks_for(n, kScanChunk);
     delete out->impl;
@@ -1091,7 +1110,7 @@ int build_bvh_resident(const double *vertices, uint64_t n64, DeviceBvh *out, std
     // per triangle: 152 B of vertices and per-triangle records, ~40 B of index arrays, 2.1 node records of 92 B,
     // 136 B of output; per level node (n / 8 of them at most) 68 B of split data and 1248 B of bins
     const auto t_reserve = std::chrono::steady_clock::now();
-    HIP_TRY_B(buf.reserve((size_t)n * 700 + (16u << 20)));
+    HIP_TRY_B(buf.reserve((size_t)n * 700 + (size_t)(top_cap > n / 8 + 1024 ? top_cap - n / 8 : 0) * 1400 + (16u << 20)));
     if (getenv("RTX_TIMING"))
         fprintf(stderr, "[rtx timing] %-22s %8.3f ms\n", "arena",
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_reserve).count());
@@ -1178,7 +1197,7 @@ int build_bvh_resident(const double *vertices, uint64_t n64, DeviceBvh *out, std
         hipLaunchKernelGGL(flag_kernel, dim3(chunks), dim3(kBlock), 0, stream, T, idx[cur], node_of[cur], n, nd, flag, local, sums);
         hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, stream, sums, chunks);
         hipLaunchKernelGGL(split_kernel, dim3(node_blocks), dim3(kBlock), 0, stream, nd, pre, flag, level_begin, level_end, counters,
-                           small_list, level);
+                           small_list, level, top_cap);
         hipLaunchKernelGGL(holes_kernel, dim3(pos_blocks), dim3(kBlock), 0, stream, node_of[cur], n, nd, pre, flag, holes, fills);
         hipLaunchKernelGGL(permute_kernel, dim3(pos_blocks), dim3(kBlock), 0, stream, idx[cur], node_of[cur], n, nd, pre, flag, holes,
                            fills, idx[cur ^ 1], node_of[cur ^ 1]);
@@ -1186,7 +1205,7 @@ int build_bvh_resident(const double *vertices, uint64_t n64, DeviceBvh *out, std
         const uint32_t big_before = host_counters.big;
         HIP_TRY_B(hipMemcpyAsync(&host_counters, counters, sizeof host_counters, hipMemcpyDeviceToHost, stream));
         HIP_TRY_B(hipStreamSynchronize(stream));
-        if (host_counters.next_id > top_cap) { *err = "BVH build: more level nodes than their bound"; return RTX_ERR_DEVICE; }
+        if (host_counters.next_id > top_cap) { *overflow = true; return RTX_OK; }
         if (host_counters.next_id != level_end) depth = (int)level + 1;
         if (host_counters.big == big_before) break;
         level_begin = level_end;

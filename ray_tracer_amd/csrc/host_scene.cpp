@@ -654,30 +654,44 @@ int32_t measure_bvh_depth(const std::vector<rtx_bvh_node> &nodes) {
     return deepest;
 }
 
-// A caller-supplied tree is walked once before any kernel may index with it: child
-// and triangle ranges in bounds, every node reached at most once (so the walk
-// terminates), every index a valid triangle.
-int validate_bvh(const HostScene &hs, std::string *err) {
+// A caller-supplied tree is walked once before any kernel or host loop may index with it: child and
+// triangle ranges in bounds, every node reached at most once (so the walk terminates), every index a
+// valid triangle, the leaves' ranges a partition of the index array (an overlap would make the
+// first-leaf-wins-ties rule ambiguous).  Records the walk never reaches -- the reference allocates
+// 2n-1 nodes and leaves those past nodesUsed uninitialised (bvh.hpp:91) -- are cut off the end of the
+// scene's copy and blanked in between, so that nothing downstream reads them.
+int validate_bvh(HostScene *scene, std::string *err) {
+    HostScene &hs = *scene;
     const uint64_t n = hs.n_triangles(), m = hs.nodes.size();
     if (m == 0 || hs.indices.size() != n) { *err = "BVH: node or index array has the wrong size"; return RTX_ERR_INVALID; }
     for (uint64_t t : hs.indices) if (t >= n) { *err = "BVH: triangle index out of range"; return RTX_ERR_INVALID; }
-    std::vector<uint8_t> seen(m, 0);
+    std::vector<uint8_t> seen(m, 0), covered(n, 0);
     std::vector<uint64_t> todo{0};
+    uint64_t last = 0, in_leaves = 0;
     while (!todo.empty()) {
         uint64_t k = todo.back();
         todo.pop_back();
         if (seen[k]) { *err = "BVH: a node is reachable twice"; return RTX_ERR_INVALID; }
         seen[k] = 1;
+        if (k > last) last = k;
         const rtx_bvh_node &nd = hs.nodes[k];
         if (nd.count == 0) {
-            if (nd.first == 0 || nd.first + 1 >= m) { *err = "BVH: child index out of range"; return RTX_ERR_INVALID; }
+            if (nd.first == 0 || nd.first >= m - 1) { *err = "BVH: child index out of range"; return RTX_ERR_INVALID; }
             todo.push_back(nd.first);
             todo.push_back(nd.first + 1);
-        } else if (nd.first > n || nd.count > n - nd.first) {
-            *err = "BVH: leaf range out of range";
-            return RTX_ERR_INVALID;
+        } else {
+            if (nd.first > n || nd.count > n - nd.first) { *err = "BVH: leaf range out of range"; return RTX_ERR_INVALID; }
+            for (uint64_t j = 0; j < nd.count; j++) {
+                if (covered[nd.first + j]) { *err = "BVH: leaf ranges overlap"; return RTX_ERR_INVALID; }
+                covered[nd.first + j] = 1;
+            }
+            in_leaves += nd.count;
         }
     }
+    if (in_leaves != n) { *err = "BVH: the leaves do not cover every triangle"; return RTX_ERR_INVALID; }
+    hs.nodes.resize(last + 1);
+    for (uint64_t k = 0; k <= last; k++)
+        if (!seen[k]) hs.nodes[k] = rtx_bvh_node{{0, 0, 0}, {0, 0, 0}, 0, 0};
     return RTX_OK;
 }
 

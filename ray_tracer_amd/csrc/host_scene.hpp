@@ -63,7 +63,7 @@ int apply_preset(HostScene *hs, const std::string &preset, std::string *err);
 void setup_triangles(HostScene *hs, bool have_normals);
 int build_bvh(HostScene *hs, std::string *err);
 int32_t measure_bvh_depth(const std::vector<rtx_bvh_node> &nodes);
-int validate_bvh(const HostScene &hs, std::string *err);
+int validate_bvh(HostScene *hs, std::string *err);
 
 // memcpy spread over the worker threads (a 4K frame is 25 MB: one thread takes longer than the GPU takes to render it).
 void parallel_copy(void *dst, const void *src, size_t bytes);

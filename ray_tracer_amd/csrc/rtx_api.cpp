@@ -143,7 +143,7 @@ int finish_host_scene(rtx_host_scene *hs, bool have_normals, bool have_bvh, int 
     rtx::setup_triangles(&s, have_normals);
     std::string err;
     if (have_bvh) {
-        if (int rc = rtx::validate_bvh(s, &err)) return fail(rc, err);
+        if (int rc = rtx::validate_bvh(&s, &err)) return fail(rc, err);
         s.bvh_depth = rtx::measure_bvh_depth(s.nodes);
     } else if (builder >= 0) {
         if (int rc = build_into_host_scene(s, builder, device, &err)) return fail(rc, err);
@@ -1100,7 +1100,9 @@ int rtx_save_ppm(const char *path, int32_t width, int32_t height, const uint8_t 
 // library needed and nothing to get wrong; a 4K frame is 24.9 MB either way).
 static int save_png_impl(const char *path, int32_t width, int32_t height, const uint8_t *rgb) {
     if (!path || !rgb || width <= 0 || height <= 0) return fail(RTX_ERR_INVALID, "bad argument");
-    FILE *f = fopen(path, "wb");
+    // closed on every way out, the vectors below may throw
+    struct File { FILE *f; ~File() { if (f) fclose(f); } } file{fopen(path, "wb")};
+    FILE *f = file.f;
     if (!f) return fail(RTX_ERR_IO, "Failed to open file.\n");
     static uint32_t table[256];
     static std::once_flag once;
@@ -1165,6 +1167,7 @@ static int save_png_impl(const char *path, int32_t width, int32_t height, const 
     z.insert(z.end(), ad, ad + 4);
     chunk("IDAT", z);
     chunk("IEND", {});
+    file.f = nullptr;
     if (fclose(f) != 0 || !ok) return fail(RTX_ERR_IO, "short write");
     return RTX_OK;
 }

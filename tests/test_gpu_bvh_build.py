@@ -65,6 +65,27 @@ def test_sorted_slivers_make_a_deep_tree():
     assert host["depth"] > 12
 
 
+def test_more_level_nodes_than_estimated_builds_again_with_the_true_bound(monkeypatch):
+    """The level passes size their per-node arrays by an estimate (n / 8 + 1024 nodes of more than 64 triangles and
+    their children); a mesh that needs more must not write past them and is built again with room for 2n.  The
+    estimate is forced down here (a chain that really exceeds it needs coordinates beyond the double range)."""
+    x = np.cumsum(1.2 ** np.arange(2000))
+    v = np.zeros((2000, 9))
+    v[:, 0], v[:, 3], v[:, 6] = x, x * (1 + 1e-3), x
+    v[:, 4], v[:, 8] = 0.1, 0.1
+    host = rt.build_bvh(v, rt.BUILDER_HOST)
+    assert host["depth"] > 100
+    for estimate in ("4", "50", "300"):
+        monkeypatch.setenv("RTX_BVH_LEVEL_NODES", estimate)
+        dev = rt.build_bvh(v, rt.BUILDER_DEVICE)
+        assert dev["nodes"].tobytes() == host["nodes"].tobytes() and np.array_equal(dev["indices"], host["indices"])
+    hs = rt.HostScene.standin("bunny", 20010, seed=5)
+    want = hs.arrays()
+    monkeypatch.setenv("RTX_BVH_LEVEL_NODES", "16")
+    dev = rt.build_bvh(want["vertices"], rt.BUILDER_DEVICE)
+    assert dev["nodes"].tobytes() == want["nodes"].tobytes() and np.array_equal(dev["indices"], want["indices"])
+
+
 def test_standin_bunny_tree_and_render():
     hs = rt.HostScene.standin("bunny", 20010, seed=3)
     before = hs.arrays()

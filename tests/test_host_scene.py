@@ -127,6 +127,45 @@ def test_caller_supplied_bvh_is_validated():
         rt.HostScene.from_arrays(v, col, spec, refl, nodes=built["nodes"], indices=bad_idx, **cam)
 
 
+def test_caller_supplied_bvh_with_the_references_uninitialised_tail():
+    """The reference allocates 2n-1 nodes and leaves those past nodesUsed uninitialised (bvh.hpp:91): a caller that
+    passes the allocated length must get the same scene, whatever the tail holds; leaf ranges that overlap, leaves that
+    leave a triangle out and a child index of 2^64-1 are refused."""
+    from scenes_util import soup
+
+    v, col, spec, refl, cam = soup(5, n=60)
+    built = rt.HostScene.from_arrays(v, col, spec, refl, **cam).arrays()
+    nodes, indices = built["nodes"], built["indices"]
+    assert len(nodes) < 2 * 60 - 1
+    padded = np.zeros(2 * 60 - 1, dtype=nodes.dtype)
+    padded[: len(nodes)] = nodes
+    padded["first"][len(nodes):] = 0xDEADBEEFDEADBEEF                  # garbage where the reference has garbage
+    padded["count"][len(nodes):] = 0xFEEDFACE
+    padded["bmin"][len(nodes):] = np.nan
+    hs = rt.HostScene.from_arrays(v, col, spec, refl, nodes=padded, indices=indices, **cam)
+    got = hs.arrays()
+    assert got["nodes"].tobytes() == nodes.tobytes() and np.array_equal(got["indices"], indices)
+    leaves = np.nonzero(nodes["count"] > 0)[0]
+    overlap = nodes.copy()
+    a, b = leaves[0], leaves[1]
+    overlap["first"][b] = overlap["first"][a]                          # two leaves over the same positions
+    overlap["count"][b] = overlap["count"][a]
+    with pytest.raises(rt.RtxError) as e:
+        rt.HostScene.from_arrays(v, col, spec, refl, nodes=overlap, indices=indices, **cam)
+    assert "overlap" in str(e.value) or "cover" in str(e.value)
+    wide = nodes.copy()
+    big = leaves[np.argmax(nodes["count"][leaves])]
+    if wide["count"][big] > 1:
+        wide["count"][big] -= 1                                        # one position in no leaf
+        with pytest.raises(rt.RtxError):
+            rt.HostScene.from_arrays(v, col, spec, refl, nodes=wide, indices=indices, **cam)
+    wrap = nodes.copy()
+    inner = np.nonzero(wrap["count"] == 0)[0][0]
+    wrap["first"][inner] = 0xFFFFFFFFFFFFFFFF                          # first + 1 wraps to 0
+    with pytest.raises(rt.RtxError):
+        rt.HostScene.from_arrays(v, col, spec, refl, nodes=wrap, indices=indices, **cam)
+
+
 def test_empty_scene_is_an_error():
     with pytest.raises(rt.RtxError):
         rt.HostScene.from_arrays(np.zeros((0, 9)), np.zeros((0, 3)), np.zeros(0), np.zeros(0), camera_position=(0, 0, 0))
