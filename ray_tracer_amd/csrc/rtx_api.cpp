@@ -722,6 +722,7 @@ struct LaunchPlan {
     uint32_t block = 256;        // threads per block (a power of two, 64..256)
     uint64_t grid_blocks = 0;    // blocks of the persistent launch; 0 = nothing to render
     int n_queues = 8, macro = 8; // work distribution (see tile_order_kernel)
+    int centre_first = 1;        // a queue serves the macro tiles nearest the frame's centre first
     bool pruned = false;
 };
 
@@ -777,6 +778,7 @@ static int plan_render(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8
     // XCD's queue first.
     plan->n_queues = knob("RTX_XCD_QUEUES", 1) ? 8 : 1;
     plan->macro = std::min(64, std::max(1, knob("RTX_MACRO", 8)));
+    plan->centre_first = knob("RTX_CENTRE_FIRST", 1) ? 1 : 0;
     r.n_queues = (uint32_t)plan->n_queues;
     return RTX_OK;
 }
@@ -825,9 +827,9 @@ static int render_device_timed_impl(rtx_scene *sc, const rtx_render_params *p, v
     HIP_TRY(hipMemsetAsync(r.work, 0, rtx::kScratchHeaderBytes, st));
     // The work-queue table depends only on the launch geometry: the slot keeps it until a launch with
     // another geometry (or a smaller lane count, which moves nothing: the table sits in front) uses it.
-    const std::vector<int64_t> key = {r.W, r.H, r.tile_w, r.tile_h, r.tile_rank, r.tile_count, plan.n_queues, plan.macro};
+    const std::vector<int64_t> key = {r.W, r.H, r.tile_w, r.tile_h, r.tile_rank, r.tile_count, plan.n_queues, plan.macro, plan.centre_first};
     if (key != sc->slot_key[slot]) {
-        HIP_TRY(rtx::launch_tile_order((uint32_t *)r.tile_order, r, plan.macro, plan.n_queues, st));
+        HIP_TRY(rtx::launch_tile_order((uint32_t *)r.tile_order, r, plan.macro, plan.n_queues, plan.centre_first, st));
         sc->slot_key[slot] = key;
     }
     // Diagnostics: RTX_WAVE_LOG=<file> records every wave's start/end tick (100 MHz) of this
@@ -877,7 +879,7 @@ static int render_device_noalloc_impl(rtx_scene *sc, const rtx_render_params *p,
     plan.grid_blocks = std::min<uint64_t>(plan.grid_blocks, (rtx::kNoallocScratchBytes - fixed) / per_block);
     bind_scratch(&plan, base);
     HIP_TRY(hipMemsetAsync(r.work, 0, rtx::kScratchHeaderBytes, st));       // the last call's counters
-    HIP_TRY(rtx::launch_tile_order((uint32_t *)r.tile_order, r, plan.macro, plan.n_queues, st));
+    HIP_TRY(rtx::launch_tile_order((uint32_t *)r.tile_order, r, plan.macro, plan.n_queues, plan.centre_first, st));
     HIP_TRY(rtx::launch_render(sc->dev, r, plan.pruned, d_stats != nullptr, plan.block, (uint32_t)plan.grid_blocks, st));
     return RTX_OK;
 }

@@ -34,11 +34,11 @@ inline uint64_t render_waves(const DevRender &rp) {
 }
 
 // The scratch buffer of a render launch: 1 KiB of work counters, the work-queue table
-// (9 + owned tiles + macro tiles words, see tile_order_kernel), then the per-lane arrays.
+// (9 + owned tiles + 2 x macro tiles words, see tile_order_kernel), then the per-lane arrays.
 constexpr uint64_t kScratchHeaderBytes = 1024;
 inline uint64_t render_order_words(const DevRender &rp, int macro) {
     const uint64_t macros = (uint64_t)((rp.tiles_x + macro - 1) / macro) * (uint64_t)((rp.tiles_y + macro - 1) / macro);
-    return 9 + (uint64_t)rp.owned_tiles + macros;
+    return 9 + (uint64_t)rp.owned_tiles + 2 * macros;
 }
 inline uint64_t render_order_bytes(const DevRender &rp, int macro) { return (render_order_words(rp, macro) * 4 + 255) / 256 * 256; }
 inline uint64_t render_lane_bytes(int32_t depth) { return (4 + (uint64_t)depth) * 8 + (1 + 3 * (uint64_t)depth) * 4; }
@@ -49,7 +49,7 @@ constexpr uint64_t kNoallocScratchBytes = 32ull << 20;
 hipError_t noalloc_scratch(int device, void **ptr);
 
 // Builds the work-queue table of `rp` at d_order (render_order_words() words) on the stream.
-hipError_t launch_tile_order(uint32_t *d_order, const DevRender &rp, int macro, int n_queues, hipStream_t st);
+hipError_t launch_tile_order(uint32_t *d_order, const DevRender &rp, int macro, int n_queues, int centre_first, hipStream_t st);
 
 // 256-thread blocks of the render kernel one CU keeps resident (= its waves per SIMD)
 int render_blocks_per_cu();

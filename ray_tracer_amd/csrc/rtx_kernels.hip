@@ -909,12 +909,13 @@ __global__ void __launch_bounds__(64) top_table_kernel(const DevNode *nodes, Dev
 // tile (mx, my) belongs to queue (mx + 3 my) mod n_queues; a queue lists its macro tiles in
 // row-major order and a macro tile its own tiles in row-major order.  One block: a count per macro
 // tile, one thread per queue turns the counts into offsets, then every macro tile writes its tiles.
-// `order` has room for 9 + owned tiles + macro tiles words (the counts live behind the table).
+// `order` has room for 9 + owned tiles + 2 x macro tiles words (counts and serving order live behind the table).
 __global__ void __launch_bounds__(1024) tile_order_kernel(uint32_t *order, int tiles_x, int tiles_y, int tile_rank, int tile_count,
-                                                          uint32_t owned, int macro, int n_queues) {
+                                                          uint32_t owned, int macro, int n_queues, int centre_first) {
     const int macros_x = (tiles_x + macro - 1) / macro, macros_y = (tiles_y + macro - 1) / macro;
     const int n_macros = macros_x * macros_y;
-    uint32_t *cnt = order + 9u + owned;
+    uint32_t *cnt = order + 9u + owned;          // per macro tile: its tiles, then its offset inside its queue
+    uint32_t *seq = cnt + n_macros;              // per queue, one after the other: its macro tiles in serving order
     __shared__ uint32_t q_total[8], q_base[9];
     for (int pass = 0; pass < 2; pass++) {
         for (int m = (int)threadIdx.x; m < n_macros; m += (int)blockDim.x) {
@@ -932,15 +933,42 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(uint32_t *order, int t
         }
         __syncthreads();
         if (!pass) {
-            if ((int)threadIdx.x < n_queues) {          // counts -> offsets inside the queue
-                uint32_t run = 0;
+            if ((int)threadIdx.x < n_queues) {          // counts -> offsets inside the queue, in serving order
+                const int q = (int)threadIdx.x;
+                uint32_t first = 0, mine = 0;           // where this queue's macro tiles start in `seq`, how many
+                for (int m = 0; m < n_macros; m++) {
+                    const int qm = (m % macros_x + 3 * (m / macros_x)) % n_queues;
+                    first += qm < q;
+                    mine += qm == q;
+                }
+                uint32_t *list = seq + first;
+                uint32_t k = 0;
                 for (int m = 0; m < n_macros; m++)
-                    if ((m % macros_x + 3 * (m / macros_x)) % n_queues == (int)threadIdx.x) {
-                        const uint32_t c = cnt[m];
-                        cnt[m] = run;
-                        run += c;
+                    if ((m % macros_x + 3 * (m / macros_x)) % n_queues == q) list[k++] = (uint32_t)m;
+                // The frame's costly pixels (the model, its reflections) sit around the middle of the picture
+                // in every scene of the reference; served first, their long dependent chains run while the
+                // chip is still full, and the launch ends on cheap border tiles.  Insertion sort by distance
+                // of the macro tile from the frame's centre (a few dozen entries per queue).
+                if (centre_first && mine <= 2048u) {
+                    auto key = [&](uint32_t m) {     // squared distance from the centre, each axis in units of the frame's extent
+                        const long long dx = 2 * (long long)(m % (uint32_t)macros_x) + 1 - macros_x, dy = 2 * (long long)(m / (uint32_t)macros_x) + 1 - macros_y;
+                        return dx * dx * macros_y * macros_y + dy * dy * macros_x * macros_x;
+                    };
+                    for (uint32_t i = 1; i < mine; i++) {
+                        const uint32_t m = list[i];
+                        const long long km = key(m);
+                        uint32_t j = i;
+                        while (j > 0 && key(list[j - 1]) > km) { list[j] = list[j - 1]; j--; }
+                        list[j] = m;
                     }
-                q_total[threadIdx.x] = run;
+                }
+                uint32_t run = 0;
+                for (uint32_t i = 0; i < mine; i++) {
+                    const uint32_t m = list[i], c = cnt[m];
+                    cnt[m] = run;
+                    run += c;
+                }
+                q_total[q] = run;
             }
             __syncthreads();
             if (threadIdx.x == 0) {
@@ -990,9 +1018,9 @@ hipError_t launch_top_table(const DevNode *d_nodes, DevNode *d_top, uint32_t max
     return hipGetLastError();
 }
 
-hipError_t launch_tile_order(uint32_t *d_order, const DevRender &rp, int macro, int n_queues, hipStream_t st) {
+hipError_t launch_tile_order(uint32_t *d_order, const DevRender &rp, int macro, int n_queues, int centre_first, hipStream_t st) {
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, d_order, rp.tiles_x, rp.tiles_y, rp.tile_rank, rp.tile_count,
-                       (uint32_t)rp.owned_tiles, macro, n_queues);
+                       (uint32_t)rp.owned_tiles, macro, n_queues, centre_first);
     return hipGetLastError();
 }
 
