@@ -1275,10 +1275,14 @@ namespace {
 __global__ void flatten_nodes_kernel(const rtx_bvh_node *__restrict__ in, uint32_t n_nodes, DevNode *__restrict__ out,
                                      DevTri *__restrict__ tris, int32_t *__restrict__ tame) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    // {first, count} of reference node k as the render layout has them
+    auto first_of = [](const rtx_bvh_node &h) { return h.count == 0 ? (uint32_t)(h.first + 1) : (uint32_t)h.first; };
     if (i == 0) {
         DevNode d{};
         const double nan = __longlong_as_double(0x7ff8000000000000ll);
         for (int k = 0; k < 3; k++) { d.bmin[k] = nan; d.bmax[k] = nan; }
+        d.pad[0] = first_of(in[0]);            // slot 0 pairs with the root
+        d.pad[1] = (uint32_t)in[0].count;
         out[0] = d;
     }
     if (i >= n_nodes) return;
@@ -1293,7 +1297,13 @@ __global__ void flatten_nodes_kernel(const rtx_bvh_node *__restrict__ in, uint32
              h.bmin[k] <= h.bmax[k];
     }
     d.count = (uint32_t)h.count;
-    d.first = h.count == 0 ? (uint32_t)(h.first + 1) : (uint32_t)h.first;
+    d.first = first_of(h);
+    // an even slot (i + 1 even) is the first record of a sibling pair and repeats its sibling's {first, count}
+    if ((i & 1u) && i + 1 < n_nodes) {
+        const rtx_bvh_node sib = in[i + 1];
+        d.pad[0] = first_of(sib);
+        d.pad[1] = (uint32_t)sib.count;
+    }
     out[i + 1] = d;
     if (!ok) atomicAnd(tame, 0);
     for (uint64_t j = 0; j < h.count; j++) tris[h.first + j].leaf_first = (uint32_t)h.first;

@@ -25,6 +25,9 @@ struct alignas(64) DevNode {
     double bmax[3];
     uint32_t first;   // inner: slot of the left child (right = first + 1); leaf: first triangle position
     uint32_t count;   // 0 = inner
+    // even slot (the first record of a sibling pair): {first, count} of the odd sibling once more, so that a pair test
+    // reads 112 contiguous bytes (this record and the sibling's box) and not the sibling's last 16;
+    // odd slot: unused in `nodes`, pad[0] = the pair's slot in `nodes` in the top table
     uint32_t pad[2];
 };
 static_assert(sizeof(DevNode) == 64, "DevNode");
@@ -65,7 +68,7 @@ struct DevScene {
     // The top of the tree once more, for the render kernel's LDS: `n_top_pairs` sibling pairs
     // in breadth-first order (pair 0 = slots 0 and 1), 128 bytes each.  Inside it an inner
     // child whose own pair is in the table carries kTopFlag | pair index as `first`, and
-    // pad[0] of a pair's first record holds the pair's slot in `nodes`.
+    // pad[0] of a pair's second record holds the pair's slot in `nodes`.
     const DevNode *top;
     uint32_t n_top_pairs, top_pad;
     uint32_t n_nodes, n_tris, n_point, n_dir;

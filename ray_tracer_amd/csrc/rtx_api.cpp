@@ -512,6 +512,11 @@ static int scene_create_from_host_impl(const rtx_host_scene *hs, int32_t device,
         d.count = (uint32_t)h.count;
         d.first = h.count == 0 ? (uint32_t)(h.first + 1) : (uint32_t)h.first;
     }
+    // the first record of a sibling pair repeats the second one's {first, count} (see DevNode)
+    for (uint64_t slot = 0; slot + 1 <= m; slot += 2) {
+        nodes[slot].pad[0] = nodes[slot + 1].first;
+        nodes[slot].pad[1] = nodes[slot + 1].count;
+    }
     std::vector<rtx::DevTri> tris(n);
     std::vector<rtx::DevMat> mats(n);
     memset(tris.data(), 0, n * sizeof(rtx::DevTri));

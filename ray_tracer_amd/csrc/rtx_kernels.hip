@@ -436,19 +436,21 @@ __device__ __forceinline__ void inner_step(Lane &L, const Hot &hot, uint32_t *st
     // the sibling pair is one 128-byte line: eight 16-byte loads, one round trip -- to LDS for a pair
     // of the top table (every walk starts there, and the vector memory path is what the kernel waits
     // for), else to memory
-    d2 q0, q1, q2, q3, q4, q5, q6, q7;
+    d2 q0, q1, q2, q3, q4, q5, q6;
     const bool in_top = (L.first & kTopFlag) != 0;
+    uint32_t pair_slot = L.first;          // the pair's slot in `nodes` (a table pair carries it in its second record's padding)
     if (in_top) {
         const d2 *line = hot.top + (L.first & 0xFFFFu) * 8u;
-        q0 = line[0]; q1 = line[1]; q2 = line[2]; q3 = line[3]; q4 = line[4]; q5 = line[5]; q6 = line[6]; q7 = line[7];
+        q0 = line[0]; q1 = line[1]; q2 = line[2]; q3 = line[3]; q4 = line[4]; q5 = line[5]; q6 = line[6];
+        pair_slot = (uint32_t)__double2loint(line[7].y);
     } else {
+        // 112 of the pair's 128 bytes: the first record whole (its padding repeats the sibling's {first, count}) and the
+        // sibling's box -- seven loads; every byte a wave asks its L1 for counts here
         const d2 *line = reinterpret_cast<const d2 *>(nodes + L.first);
-        q0 = line[0]; q1 = line[1]; q2 = line[2]; q3 = line[3]; q4 = line[4]; q5 = line[5]; q6 = line[6]; q7 = line[7];
-        pin(q0); pin(q1); pin(q2); pin(q3); pin(q4); pin(q5); pin(q6); pin(q7);
+        q0 = line[0]; q1 = line[1]; q2 = line[2]; q3 = line[3]; q4 = line[4]; q5 = line[5]; q6 = line[6];
+        pin(q0); pin(q1); pin(q2); pin(q3); pin(q4); pin(q5); pin(q6);
     }
     const bool root_pair = (L.first & ~kTopFlag) == 0;                   // slots (0, 1)
-    // the pair's slot in `nodes` (a table pair carries it in its first record's padding)
-    const uint32_t pair_slot = in_top ? (uint32_t)__double2loint(q3.y) : L.first;
     const double a_lo[3] = {q0.x, q0.y, q1.x}, a_hi[3] = {q1.y, q2.x, q2.y};
     const double b_lo[3] = {q4.x, q4.y, q5.x}, b_hi[3] = {q5.y, q6.x, q6.y};
     double ta, tb;
@@ -473,9 +475,9 @@ __device__ __forceinline__ void inner_step(Lane &L, const Hot &hot, uint32_t *st
         ha = ha && !beyond_a;
         hb = hb && !beyond_b;
     }
-    // {first, count} of each child sit in the fourth 16-byte piece of its record
+    // {first, count} of both children sit in the fourth 16-byte piece of the first record
     const uint32_t af = (uint32_t)__double2loint(q3.x), ac = (uint32_t)__double2hiint(q3.x);
-    const uint32_t bf = (uint32_t)__double2loint(q7.x), bc = (uint32_t)__double2hiint(q7.x);
+    const uint32_t bf = (uint32_t)__double2loint(q3.y), bc = (uint32_t)__double2hiint(q3.y);
     // next node: the only child hit, or of two the nearer one (PRUNE) / the left one; the other
     // one of two goes on the stack
     const bool take_b = hb && (!ha || (PRUNE && tb < ta));
@@ -897,7 +899,9 @@ __global__ void __launch_bounds__(64) top_table_kernel(const DevNode *nodes, Dev
         // an inner child whose pair still fits is referred to by its place in the table; slot 0 is no node
         if (s != 0 && a.count == 0 && n < max_pairs) { slot_of[n] = a.first; a.first = kTopFlag | n; n++; }
         if (b.count == 0 && n < max_pairs) { slot_of[n] = b.first; b.first = kTopFlag | n; n++; }
-        a.pad[0] = s;
+        a.pad[0] = b.first;      // the sibling's {first, count} once more, as in `nodes`
+        a.pad[1] = b.count;
+        b.pad[0] = s;
         top[2 * i] = a;
         top[2 * i + 1] = b;
     }
