@@ -1,14 +1,14 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): one rocprofv3 run per counter group over the native
 # driver, each under its own time limit; CSVs land in gpurun_out/pmc/<tag>/<pass>/.
-# usage: tools/pmc_passes.sh <tag> <scene> <standin-tris|0> <W> <H> <mode>
+# usage: tools/pmc_passes.sh <tag> <scene> <standin-tris|0> <W> <H> <mode> [knot]
 set -u
-TAG=$1; SCENE=$2; TRIS=$3; W=$4; H=$5; MODE=$6
+TAG=$1; SCENE=$2; TRIS=$3; W=$4; H=$5; MODE=$6; FAMILY=${7:-}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-if [ "$TRIS" != "0" ]; then SRC="--standin $TRIS"; else SRC="--obj $ROOT/tests/golden/$SCENE.obj"; fi
+if [ "$TRIS" != "0" ]; then SRC="--standin $TRIS"; [ "$FAMILY" = "knot" ] && SRC="$SRC --knot"; else SRC="--obj $ROOT/tests/golden/$SCENE.obj"; fi
 ARGS="--scene $SCENE $SRC --width $W --height $H --mode $MODE --repeats 3 --out /tmp/pmc_canvas.ppm"
 run() {  # name, counters...
   local name=$1; shift
