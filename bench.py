@@ -116,7 +116,8 @@ def main():
     ap.add_argument("--obj", default=None, help="real .obj for the scene (default: the seeded stand-in mesh)")
     ap.add_argument("--tolerant", action="store_true",
                     help="read --obj with the general loader (vt/vn index groups, negative indices, comments) instead of the "
-                         "reference's grammar")
+                         "reference's grammar; the last face is read twice, as the reference's own pipeline (tools/denormalize.py, "
+                         "then parseOBJ) reads it, so that triangle ids and materials match the reference's render of the mesh")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo stages the tile gather through host memory: a rehearsal of the N > 1 path on a box with fewer "
@@ -185,7 +186,7 @@ def main():
     obj_path = os.path.join(obj_dir, f"{args.scene}.obj")
     t0 = time.time()
     if args.obj:
-        host = rt.HostScene.load_obj(args.obj, args.scene, no_bvh=True, tolerant=args.tolerant)
+        host = rt.HostScene.load_obj(args.obj, args.scene, no_bvh=True, tolerant=args.tolerant, last_face_twice=args.tolerant)
         data = "real mesh"
         obj_path = args.obj
     else:

@@ -110,7 +110,12 @@ enum {
     RTX_LOAD_DEVICE_BVH = 2,     /* build the BVH with RTX_BUILDER_DEVICE (same arrays, copied back)        */
     RTX_LOAD_TOLERANT = 4,       /* general OBJ text instead of the reference's dialect, see below          */
     RTX_LOAD_NO_BVH = 8,         /* no BVH on the host: rtx_scene_create_from_host builds it on the device  */
-    RTX_STANDIN_KNOT = 16        /* rtx_host_scene_standin_ex only: the knotted-tube stand-in, see below    */
+    RTX_STANDIN_KNOT = 16,       /* rtx_host_scene_standin_ex only: the knotted-tube stand-in, see below    */
+    RTX_LOAD_LAST_FACE_TWICE = 32 /* with RTX_LOAD_TOLERANT: the last face once more, as the reference's own
+                                     pipeline yields it (tools/denormalize.py ends its output with a newline,
+                                     after which parseOBJ reads the last face twice, include/scene.hpp:223-246):
+                                     triangle count, ids and the presets' last-ten materials then match a frame
+                                     the reference renders from the same source mesh                         */
 };
 
 /* The call above with options.  RTX_LOAD_TOLERANT reads OBJ files the reference's loader

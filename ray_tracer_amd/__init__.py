@@ -206,7 +206,7 @@ def _dptr(a: np.ndarray, ctype):
 
 NODE_DTYPE = np.dtype([("bmin", "<f8", 3), ("bmax", "<f8", 3), ("first", "<u8"), ("count", "<u8")])
 BUILDER_HOST, BUILDER_DEVICE = 0, 1
-LOAD_VERBOSE, LOAD_DEVICE_BVH, LOAD_TOLERANT, LOAD_NO_BVH, STANDIN_KNOT = 1, 2, 4, 8, 16
+LOAD_VERBOSE, LOAD_DEVICE_BVH, LOAD_TOLERANT, LOAD_NO_BVH, STANDIN_KNOT, LOAD_LAST_FACE_TWICE = 1, 2, 4, 8, 16, 32
 
 
 def build_bvh(vertices, builder: int = BUILDER_DEVICE, device: int = -1) -> dict:
@@ -302,10 +302,10 @@ class HostScene:
 
     @classmethod
     def load_obj(cls, path: str, preset: str, verbose: bool = False, *, device_bvh: bool = False, tolerant: bool = False,
-                 no_bvh: bool = False, device: int = -1) -> "HostScene":
+                 no_bvh: bool = False, device: int = -1, last_face_twice: bool = False) -> "HostScene":
         h = C.c_void_p()
         flags = ((LOAD_VERBOSE if verbose else 0) | (LOAD_DEVICE_BVH if device_bvh else 0) | (LOAD_TOLERANT if tolerant else 0) |
-                 (LOAD_NO_BVH if no_bvh else 0))
+                 (LOAD_NO_BVH if no_bvh else 0) | (LOAD_LAST_FACE_TWICE if last_face_twice else 0))
         _check(lib().rtx_host_scene_load_obj_ex(os.fsencode(path), preset.encode(), flags, device, C.byref(h)))
         return cls(h)
 

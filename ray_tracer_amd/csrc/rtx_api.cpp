@@ -300,6 +300,10 @@ static int host_scene_load_obj_ex_impl(const char *obj_path, const char *preset,
     std::string err;
     int rc = (flags & RTX_LOAD_TOLERANT) ? rtx::parse_obj_tolerant(obj_path, &hs->s.vertices, &err)
                                          : rtx::parse_obj(obj_path, &hs->s.vertices, &err);
+    if (rc == RTX_OK && (flags & RTX_LOAD_TOLERANT) && (flags & RTX_LOAD_LAST_FACE_TWICE) && hs->s.vertices.size() >= 9) {
+        const size_t at = hs->s.vertices.size() - 9;
+        for (size_t k = 0; k < 9; k++) hs->s.vertices.push_back(hs->s.vertices[at + k]);
+    }
     // Scene::parseOBJ prints the face count (scene.hpp:248)
     if (rc == RTX_OK && verbose) printf("[ TRI ] %zu triangles.\n", hs->s.vertices.size() / 9);
     if (rc == RTX_OK) rc = rtx::apply_preset(&hs->s, preset, &err);

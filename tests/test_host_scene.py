@@ -304,6 +304,14 @@ def test_tolerant_loader_equals_the_reference_script_followed_by_the_strict_load
     tolerant = rt.HostScene.load_obj(str(tmp_path / "scenes" / "bunny-o.obj"), "teapot", tolerant=True, no_bvh=True).arrays()["vertices"]
     assert tolerant.shape == (nf, 9) and strict.shape == (nf + 1, 9)
     assert strict[:nf].tobytes() == tolerant.tobytes() and strict[nf].tobytes() == strict[nf - 1].tobytes()
+    # RTX_LOAD_LAST_FACE_TWICE: the tolerant loader on the original yields the pipeline's scene, materials included (the
+    # presets address the last ten triangles from the END of the list, so one triangle more shifts them)
+    a = rt.HostScene.load_obj(str(tmp_path / "scenes" / "bunny.obj"), "bunny").arrays()
+    b = rt.HostScene.load_obj(str(tmp_path / "scenes" / "bunny-o.obj"), "bunny", tolerant=True, last_face_twice=True).arrays()
+    for key in ("vertices", "normals", "colors", "specularity", "reflectivity", "nodes", "indices"):
+        assert a[key].tobytes() == b[key].tobytes(), key
+    c = rt.HostScene.load_obj(str(tmp_path / "scenes" / "bunny-o.obj"), "bunny", tolerant=True).arrays()
+    assert not np.array_equal(c["reflectivity"], a["reflectivity"][:nf])          # without the flag the overrides sit one triangle earlier
 
 
 @pytest.mark.parametrize("w,h", [(1, 1), (7, 5), (300, 217), (1920, 37)])
