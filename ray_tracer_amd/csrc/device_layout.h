@@ -113,7 +113,7 @@ struct DevRender {
     int32_t tail_lanes;                 // at most this many live lanes: run every kind of step each round
     int32_t also_lanes;                 // a kind with at least this many waiting lanes runs in every round
     int32_t also_leaf, also_shade;      // (inner node steps: also_lanes; triangle steps: also_leaf; shading: also_shade)
-    unsigned long long *wave_log;       // diagnostics: {start, end} 100 MHz ticks per wave, or NULL
+    unsigned long long *wave_log;       // diagnostics, or NULL: per wave {start, end, latest block drawn} in 100 MHz ticks and that block (x0 | y0 << 16 | queue << 32)
     unsigned long long *ticks;          // {earliest block start, latest block end} in 100 MHz ticks, or NULL
 };
 

@@ -797,6 +797,10 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
                         block_packed0 = (local_tile * (uint32_t)rp.tile_h + by) * (uint32_t)rp.tile_w + bx;
                         cursor = 0;
                         drained = false;
+                        if (rp.wave_log && lane == 0) {      // diagnostics: when and where this wave drew its latest block
+                            rp.wave_log[4 * gw + 2] = wall_clock64();
+                            rp.wave_log[4 * gw + 3] = (unsigned long long)block_x0 | ((unsigned long long)block_y0 << 16) | ((unsigned long long)q << 32);
+                        }
                     }
                 }
                 if (cursor == 64u) {                                    // nothing left anywhere
@@ -836,8 +840,8 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
             }
     }
     if (rp.wave_log && lane == 0) {
-        rp.wave_log[2 * gw] = wave_t0;
-        rp.wave_log[2 * gw + 1] = wall_clock64();
+        rp.wave_log[4 * gw] = wave_t0;
+        rp.wave_log[4 * gw + 1] = wall_clock64();
     }
     // first wave start / last wave end of the launch, one pair of atomics per block
     if (rp.ticks && threadIdx.x == 0) {
