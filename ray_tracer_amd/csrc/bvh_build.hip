@@ -749,6 +749,15 @@ __global__ __launch_bounds__(kBlock) void subtree_kernel(const TriRec *__restric
         }
     }
 
+    // half the surface of the triangle's own box (AABB::area, bvh.hpp:74-78), what it adds to a split's cost when it is alone on its side
+    double own_area = 0;
+    if (active) {
+        double l3[3], h3[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { l3[k] = value_of(lo[k]); h3[k] = value_of(hi[k]); }
+        own_area = half_area(l3, h3);
+    }
+
     // pending nodes: entry e lives in lane e
     uint32_t st_range = 0, st_id = 0, st_run = 0;
     int sp = 0;
@@ -828,7 +837,42 @@ __global__ __launch_bounds__(kBlock) void subtree_kernel(const TriRec *__restric
         // findBestSplitPlane (bvh.hpp:236-305)
         double best = inf, best_pos = 0;
         int best_axis = -1;
-        if (cnt >= 2) {
+        bool pair_done = false;
+        if (cnt == 2) {
+            // Two triangles, the commonest inner node by far.  On an axis where the centroids differ the one with the
+            // smaller centroid falls in bin 0 ((c - cmin) * scale = 0) and the other in bin 7 (d * (8 / d) is within an
+            // ulp of 8, clamped), so all seven planes of every such axis cut between them at the same cost,
+            // area(one) + area(other) (1 * x = x, and a sum does not depend on the order of its terms): the scan of
+            // bvh.hpp:268-302 keeps the first, plane 0 of the lowest axis.  Centroid differences so small or large that 8 / d
+            // overflows or underflows (or that are not numbers) take the general path.
+            double cmin[3], cmax[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { cmin[k] = value_of(cbox_k[k]); cmax[k] = value_of(cbox_k[3 + k]); }
+            const uint64_t both = __ballot(member);
+            const int la = __ffsll((unsigned long long)both) - 1, lb = 63 - __clzll((unsigned long long)both);
+            const double area_sum = __longlong_as_double((long long)readlane64((uint64_t)__double_as_longlong(own_area), la)) +
+                                    __longlong_as_double((long long)readlane64((uint64_t)__double_as_longlong(own_area), lb));
+            int ax = -1;
+            bool tame = true;
+#pragma unroll
+            for (int k = 2; k >= 0; k--)
+                if (cmin[k] != cmax[k]) {
+                    ax = k;
+                    tame = tame && (cmax[k] - cmin[k]) >= 0x1p-1000 && (cmax[k] - cmin[k]) <= 0x1p1000;
+                }
+            if (tame) {
+                pair_done = true;
+                if (ax >= 0 && area_sum < inf) {
+                    const double lo_c = ax == 0 ? cmin[0] : ax == 1 ? cmin[1] : cmin[2];
+                    const double hi_c = ax == 0 ? cmax[0] : ax == 1 ? cmax[1] : cmax[2];
+                    const double width = (hi_c - lo_c) / kBins;
+                    best = area_sum;
+                    best_axis = ax;
+                    best_pos = lo_c + width * static_cast<double>(1);
+                }
+            }
+        }
+        if (cnt >= 2 && !pair_done) {
             double cmin[3], cmax[3];
 #pragma unroll
             for (int k = 0; k < 3; k++) { cmin[k] = value_of(cbox_k[k]); cmax[k] = value_of(cbox_k[3 + k]); }
