@@ -174,6 +174,47 @@ __device__ __forceinline__ uint64_t run_reduce(uint64_t v, uint32_t node, int la
     return v;
 }
 
+// Wave reductions without trips through memory: four DPP exchanges inside rows of 16 lanes
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror), one ds_swizzle
+// across the rows of a half wave (lane ^ 16) and two readlanes across the halves.  The
+// result is uniform.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ uint64_t dpp64(uint64_t v) {
+    return ((uint64_t)dpp32<CTRL>((uint32_t)(v >> 32)) << 32) | dpp32<CTRL>((uint32_t)v);
+}
+__device__ __forceinline__ uint32_t swz16_32(uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F); }
+__device__ __forceinline__ uint64_t swz16_64(uint64_t v) {
+    return ((uint64_t)swz16_32((uint32_t)(v >> 32)) << 32) | swz16_32((uint32_t)v);
+}
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int src) {
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src), hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+template <bool IS_MIN>
+__device__ __forceinline__ uint64_t pick64(uint64_t a, uint64_t b) { return IS_MIN ? (b < a ? b : a) : (b > a ? b : a); }
+template <bool IS_MIN>
+__device__ __forceinline__ uint64_t wave_reduce64(uint64_t v) {
+    v = pick64<IS_MIN>(v, dpp64<0xB1>(v));
+    v = pick64<IS_MIN>(v, dpp64<0x4E>(v));
+    v = pick64<IS_MIN>(v, dpp64<0x141>(v));
+    v = pick64<IS_MIN>(v, dpp64<0x140>(v));
+    v = pick64<IS_MIN>(v, swz16_64(v));
+    return pick64<IS_MIN>(readlane64(v, 0), readlane64(v, 32));
+}
+__device__ __forceinline__ uint32_t wave_max32(uint32_t v) {
+    uint32_t o;
+    o = dpp32<0xB1>(v); v = o > v ? o : v;
+    o = dpp32<0x4E>(v); v = o > v ? o : v;
+    o = dpp32<0x141>(v); v = o > v ? o : v;
+    o = dpp32<0x140>(v); v = o > v ? o : v;
+    o = swz16_32(v); v = o > v ? o : v;
+    const uint32_t x = __builtin_amdgcn_readlane(v, 0), y = __builtin_amdgcn_readlane(v, 32);
+    return x > y ? x : y;
+}
 // updateNodeBounds (bvh.hpp:100-115) for every node of the new level at once, plus the
 // centroid bounds findBestSplitPlane starts with (bvh.hpp:242-250).
 // A block walks `tiles_per_block` consecutive tiles of kFat positions.  Tiles that lie
@@ -226,17 +267,32 @@ __global__ __launch_bounds__(kFat) void bounds_kernel(const TriRec *__restrict__
 #pragma unroll
             for (int k = 0; k < 3; k++) { lo[k] = clo[k] = kKeyMinInit; hi[k] = chi[k] = kKeyMaxInit; zs[k] = 0; }
         }
+        bool tail;
+        if (uniform) {
+            // every lane of the tile (bar the ones past the end, which hold the neutral values) belongs to one node: plain
+            // wave reductions, no segment bookkeeping and no trips through the LDS crossbar
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            lo[k] = run_reduce<true>(lo[k], node, lane);
-            hi[k] = run_reduce<false>(hi[k], node, lane);
-            clo[k] = run_reduce<true>(clo[k], node, lane);
-            chi[k] = run_reduce<false>(chi[k], node, lane);
-            zs[k] = run_reduce<false>(zs[k], node, lane);
+            for (int k = 0; k < 3; k++) {
+                lo[k] = wave_reduce64<true>(lo[k]);
+                hi[k] = wave_reduce64<false>(hi[k]);
+                clo[k] = wave_reduce64<true>(clo[k]);
+                chi[k] = wave_reduce64<false>(chi[k]);
+                zs[k] = wave_reduce64<false>(zs[k]);
+            }
+            tail = lane == 0 && __ballot(node != kInactive) != 0;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                lo[k] = run_reduce<true>(lo[k], node, lane);
+                hi[k] = run_reduce<false>(hi[k], node, lane);
+                clo[k] = run_reduce<true>(clo[k], node, lane);
+                chi[k] = run_reduce<false>(chi[k], node, lane);
+                zs[k] = run_reduce<false>(zs[k], node, lane);
+            }
+            const uint32_t next = __shfl_down(node, 1);
+            tail = (lane == 63 || next != node) && node != kInactive;
         }
-        const uint32_t next = __shfl_down(node, 1);
-        const bool tail = lane == 63 || next != node;
-        if (tail && node != kInactive) {
+        if (tail) {
             unsigned long long *box = uniform ? s_acc : (unsigned long long *)nd.box + 6 * (size_t)node;
             unsigned long long *cbox = uniform ? s_acc + 6 : (unsigned long long *)nd.cbox + 6 * (size_t)node;
             unsigned long long *zero = uniform ? s_acc + 12 : (unsigned long long *)nd.zero + 3 * (size_t)node;
@@ -628,47 +684,6 @@ __global__ void permute_kernel(const uint32_t *__restrict__ idx, const uint32_t 
 
 // ---- one wave builds a whole small subtree -------------------------------------------
 
-// Wave reductions without trips through memory: four DPP exchanges inside rows of 16 lanes
-// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror), one ds_swizzle
-// across the rows of a half wave (lane ^ 16) and two readlanes across the halves.  The
-// result is uniform.
-template <int CTRL>
-__device__ __forceinline__ uint32_t dpp32(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
-}
-template <int CTRL>
-__device__ __forceinline__ uint64_t dpp64(uint64_t v) {
-    return ((uint64_t)dpp32<CTRL>((uint32_t)(v >> 32)) << 32) | dpp32<CTRL>((uint32_t)v);
-}
-__device__ __forceinline__ uint32_t swz16_32(uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F); }
-__device__ __forceinline__ uint64_t swz16_64(uint64_t v) {
-    return ((uint64_t)swz16_32((uint32_t)(v >> 32)) << 32) | swz16_32((uint32_t)v);
-}
-__device__ __forceinline__ uint64_t readlane64(uint64_t v, int src) {
-    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src), hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src);
-    return ((uint64_t)hi << 32) | lo;
-}
-template <bool IS_MIN>
-__device__ __forceinline__ uint64_t pick64(uint64_t a, uint64_t b) { return IS_MIN ? (b < a ? b : a) : (b > a ? b : a); }
-template <bool IS_MIN>
-__device__ __forceinline__ uint64_t wave_reduce64(uint64_t v) {
-    v = pick64<IS_MIN>(v, dpp64<0xB1>(v));
-    v = pick64<IS_MIN>(v, dpp64<0x4E>(v));
-    v = pick64<IS_MIN>(v, dpp64<0x141>(v));
-    v = pick64<IS_MIN>(v, dpp64<0x140>(v));
-    v = pick64<IS_MIN>(v, swz16_64(v));
-    return pick64<IS_MIN>(readlane64(v, 0), readlane64(v, 32));
-}
-__device__ __forceinline__ uint32_t wave_max32(uint32_t v) {
-    uint32_t o;
-    o = dpp32<0xB1>(v); v = o > v ? o : v;
-    o = dpp32<0x4E>(v); v = o > v ? o : v;
-    o = dpp32<0x141>(v); v = o > v ? o : v;
-    o = dpp32<0x140>(v); v = o > v ? o : v;
-    o = swz16_32(v); v = o > v ? o : v;
-    const uint32_t x = __builtin_amdgcn_readlane(v, 0), y = __builtin_amdgcn_readlane(v, 32);
-    return x > y ? x : y;
-}
 // Smallest cost over the wave; on equal costs the smallest tag.
 __device__ __forceinline__ void wave_argmin(double &cost, int &tag) {
     auto step = [&](uint64_t oc_bits, uint32_t ot) {
