@@ -3,6 +3,9 @@
 #ifndef RTX_BVH_BUILD_H
 #define RTX_BVH_BUILD_H
 
+#include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <cstdint>
 #include <string>
 
@@ -28,8 +31,17 @@ struct DeviceBvh {
     DeviceBvh &operator=(const DeviceBvh &) = delete;
 };
 
+// Ordinary (pageable) host memory -> device memory of the current device at the rate of pinned memory: the bytes pass
+// through a small ring of pinned buffers kept by the process, the copy into the ring overlapping the previous piece's DMA
+// (the runtime's own path for pageable memory reaches half the link's rate).  Ordered on `stream`; returns when the
+// last piece has landed.  Callers take turns: a second upload waits for the first.
+hipError_t upload_pageable(void *dst, const void *src, size_t bytes, hipStream_t stream);
+
 // Builds on the current HIP device from 9 doubles per triangle (host memory).
-int build_bvh_resident(const double *vertices, uint64_t n_triangles, DeviceBvh *out, std::string *err);
+// *vertices_up (optional) is set to 1 once the vertices are on the device -- or the build has failed before --
+// so that a caller's other uploads can queue behind them.
+int build_bvh_resident(const double *vertices, uint64_t n_triangles, DeviceBvh *out, std::string *err,
+                       std::atomic<int> *vertices_up = nullptr);
 
 // The same, copied to host arrays: nodes_out holds 2n-1 records, indices_out n.
 int build_bvh_device(const double *vertices, uint64_t n_triangles, rtx_bvh_node *nodes_out, uint64_t *indices_out,

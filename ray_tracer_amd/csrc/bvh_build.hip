@@ -31,11 +31,16 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bvh_build.h"
@@ -1139,11 +1144,79 @@ struct DeviceBvh::Impl {
 DeviceBvh::DeviceBvh() = default;
 DeviceBvh::~DeviceBvh() { delete impl; }
 
+hipError_t upload_pageable(void *dst, const void *src, size_t bytes, hipStream_t stream) {
+    constexpr size_t kPiece = 4u << 20;
+    constexpr int kThreads = 4, kRing = 2;
+    // what was queued on `stream` before comes first, as with a plain copy
+    hipError_t e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    if (bytes < 8 * kPiece) {
+        e = bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream) : hipSuccess;
+        return e == hipSuccess ? hipStreamSynchronize(stream) : e;
+    }
+    // One host thread fills pinned memory slower than the link drains it: kThreads of them take the pieces in turn, each
+    // with two pinned buffers and a stream of its own, so that filling one buffer overlaps the DMA of the other.
+    static std::mutex turn;
+    static void *ring[kThreads][kRing] = {};        // pinned, visible to every device; kept until the process ends
+    std::lock_guard<std::mutex> hold(turn);
+    for (int t = 0; t < kThreads; t++)
+        for (int k = 0; k < kRing; k++)
+            if (!ring[t][k]) {
+                e = hipHostMalloc(&ring[t][k], kPiece, hipHostMallocPortable);
+                if (e != hipSuccess) { ring[t][k] = nullptr; return e; }
+            }
+    int device = 0;
+    e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    // streams and events are made once per device and kept: creating one takes the runtime's lock, which would hold up
+    // the kernel launches of whoever builds a tree meanwhile
+    struct Lanes { hipStream_t s[kThreads] = {}; hipEvent_t landed[kThreads][kRing] = {}; };
+    static std::map<int, Lanes> per_device;
+    Lanes &lanes = per_device[device];
+    for (int t = 0; t < kThreads; t++) {
+        if (!lanes.s[t]) {
+            e = hipStreamCreateWithFlags(&lanes.s[t], hipStreamNonBlocking);
+            if (e != hipSuccess) { lanes.s[t] = nullptr; return e; }
+        }
+        for (int k = 0; k < kRing; k++)
+            if (!lanes.landed[t][k]) {
+                e = hipEventCreateWithFlags(&lanes.landed[t][k], hipEventDisableTiming);
+                if (e != hipSuccess) { lanes.landed[t][k] = nullptr; return e; }
+            }
+    }
+    const size_t n_pieces = (bytes + kPiece - 1) / kPiece;
+    hipError_t result[kThreads];
+    auto work = [&](int t) {
+        hipError_t r = hipSetDevice(device);
+        size_t round = 0;
+        for (size_t i = (size_t)t; i < n_pieces && r == hipSuccess; i += kThreads, round++) {
+            const int k = (int)(round % kRing);
+            const size_t off = i * kPiece, len = std::min(kPiece, bytes - off);
+            if (round >= (size_t)kRing) r = hipEventSynchronize(lanes.landed[t][k]);     // the buffer's previous piece has left it
+            if (r != hipSuccess) break;
+            memcpy(ring[t][k], static_cast<const char *>(src) + off, len);
+            r = hipMemcpyAsync(static_cast<char *>(dst) + off, ring[t][k], len, hipMemcpyHostToDevice, lanes.s[t]);
+            if (r == hipSuccess) r = hipEventRecord(lanes.landed[t][k], lanes.s[t]);
+        }
+        // the buffers are the next caller's: every piece must have left them before the turn ends
+        const hipError_t drained = hipStreamSynchronize(lanes.s[t]);
+        result[t] = r == hipSuccess ? drained : r;
+    };
+    std::thread helpers[kThreads - 1];
+    for (int t = 1; t < kThreads; t++) helpers[t - 1] = std::thread(work, t);
+    work(0);
+    for (std::thread &h : helpers) h.join();
+    for (int t = 0; t < kThreads; t++) if (result[t] != hipSuccess) return result[t];
+    return hipSuccess;
+}
+
 // One attempt with room for `top_cap` nodes in the level passes (nodes of more than kSmall triangles and their
 // children).  *overflow: the mesh needs more of them; nothing was written out of bounds.
-static int build_resident_attempt(const double *vertices, uint32_t n, uint32_t top_cap, DeviceBvh *out, std::string *err, bool *overflow);
+static int build_resident_attempt(const double *vertices, uint32_t n, uint32_t top_cap, DeviceBvh *out, std::string *err, bool *overflow,
+                                  std::atomic<int> *vertices_up);
 
-int build_bvh_resident(const double *vertices, uint64_t n64, DeviceBvh *out, std::string *err) {
+int build_bvh_resident(const double *vertices, uint64_t n64, DeviceBvh *out, std::string *err, std::atomic<int> *vertices_up) {
+    struct Release { std::atomic<int> *f; ~Release() { if (f) f->store(1); } } release{vertices_up};   // whatever happens below
     if (n64 == 0) { *err = "cannot build a BVH over zero triangles"; return RTX_ERR_INVALID; }
     if (n64 >= (1ull << 28)) { *err = "more than 2^28 triangles"; return RTX_ERR_UNSUPPORTED; }
     const uint32_t n = (uint32_t)n64;
@@ -1153,13 +1226,14 @@ int build_bvh_resident(const double *vertices, uint64_t n64, DeviceBvh *out, std
     bool overflow = false;
     uint32_t estimate = n / 8 + 1024;
     if (const char *v = getenv("RTX_BVH_LEVEL_NODES")) estimate = (uint32_t)std::max(4, atoi(v));   // tests: force the second attempt
-    int rc = build_resident_attempt(vertices, n, estimate, out, err, &overflow);
-    if (overflow) rc = build_resident_attempt(vertices, n, 2 * n + 2, out, err, &overflow);
+    int rc = build_resident_attempt(vertices, n, estimate, out, err, &overflow, vertices_up);
+    if (overflow) rc = build_resident_attempt(vertices, n, 2 * n + 2, out, err, &overflow, vertices_up);
     if (overflow) { *err = "BVH build: more level nodes than their bound"; return RTX_ERR_DEVICE; }
     return rc;
 }
 
-static int build_resident_attempt(const double *vertices, uint32_t n, uint32_t top_cap, DeviceBvh *out, std::string *err, bool *overflow) {
+static int build_resident_attempt(const double *vertices, uint32_t n, uint32_t top_cap, DeviceBvh *out, std::string *err, bool *overflow,
+                                  std::atomic<int> *vertices_up) {
     *overflow = false;
     const uint32_t cap = top_cap + 2 * n;            // + 2m-2 reserved ids per small root
     const uint32_t chunks = blocks_for(n, kScanChunk);
@@ -1208,7 +1282,8 @@ static int build_resident_attempt(const double *vertices, uint32_t n, uint32_t t
     struct EventGuard { hipEvent_t a, b; ~EventGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } guard{ev0, ev1};
     const bool timing = getenv("RTX_TIMING") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
-    HIP_TRY_B(hipMemcpy(V, vertices, 9 * (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY_B(upload_pageable(V, vertices, 9 * (size_t)n * sizeof(double), stream));
+    if (vertices_up) vertices_up->store(1);
     if (timing)
         fprintf(stderr, "[rtx timing] %-22s %8.3f ms\n", "vertices up",
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -552,7 +553,7 @@ static int scene_create_from_host_impl(const rtx_host_scene *hs, int32_t device,
         hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
         if (e != hipSuccess) return e;
         sc->bytes += bytes;
-        return bytes ? hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+        return bytes ? rtx::upload_pageable(*dst, src, bytes, nullptr) : hipSuccess;
     };
     hipError_t e = upload(&sc->d_nodes, nodes.data(), nodes.size() * sizeof(rtx::DevNode));
     if (e == hipSuccess) e = upload(&sc->d_tris, tris.data(), n * sizeof(rtx::DevTri));
@@ -598,16 +599,18 @@ static int create_scene_built_on_device(const rtx_scene_desc *d, rtx_scene **out
     // helper thread and its own stream while this thread builds the tree: the copy engine is idle during the build.
     struct Temp { void *p = nullptr; ~Temp() { (void)hipFree(p); } } t_normals, t_colors, t_spec, t_refl;
     hipError_t staged = hipSuccess;
+    std::atomic<int> vertices_up{0};
     std::thread uploader([&]() {
         hipStream_t up = nullptr;
         hipError_t e = hipSetDevice(device);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
         auto stage = [&](Temp &t, const void *src, size_t bytes) {
             if (e == hipSuccess) e = hipMalloc(&t.p, bytes);
-            if (e == hipSuccess) e = hipMemcpyAsync(t.p, src, bytes, hipMemcpyHostToDevice, up);
+            if (e == hipSuccess) e = rtx::upload_pageable(t.p, src, bytes, up);      // waits its turn behind the vertices
         };
         if (e == hipSuccess) e = hipMalloc(&sc->d_tris, n * sizeof(rtx::DevTri));
         if (e == hipSuccess) e = hipMalloc(&sc->d_mats, n * sizeof(rtx::DevMat));
+        while (!vertices_up.load()) std::this_thread::yield();      // the build waits for the vertices, nothing waits for these
         if (d->normals) stage(t_normals, d->normals, 3 * n * sizeof(double));
         stage(t_colors, d->colors, 3 * n * sizeof(int32_t));
         stage(t_spec, d->specularity, n * sizeof(int32_t));
@@ -617,7 +620,7 @@ static int create_scene_built_on_device(const rtx_scene_desc *d, rtx_scene **out
         staged = e;
     });
     struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join_on_exit{uploader};
-    const int build_rc = rtx::build_bvh_resident(d->vertices, n, &bvh, &err);
+    const int build_rc = rtx::build_bvh_resident(d->vertices, n, &bvh, &err, &vertices_up);
     uploader.join();
     if (build_rc != RTX_OK) return fail(build_rc, err);
     timer.lap("upload + BVH build");
