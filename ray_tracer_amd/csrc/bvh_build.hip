@@ -1032,9 +1032,29 @@ __global__ __launch_bounds__(kBlock) void subtree_kernel(const TriRec *__restric
                     nd.first[child] = f0 + a; nd.count[child] = nl; nd.parent[child] = id; nd.link[child] = (run + 1) << 1;
                     nd.first[child + 1] = f0 + a + nl; nd.count[child + 1] = cnt - nl; nd.parent[child + 1] = id; nd.link[child + 1] = 1u;
                 }
-                if (lane == sp) { st_range = (a + nl) | (b << 8) | ((lev + 1) << 16); st_id = child + 1; st_run = 0; }
-                if (lane == sp + 1) { st_range = a | ((a + nl) << 8) | ((lev + 1) << 16); st_id = child; st_run = run + 1; }
-                sp += 2;
+                // A child of one triangle -- half of all nodes -- is finished here by the lane that holds the triangle:
+                // its box is the triangle's, it cannot be split (bvh.hpp:252 skips every axis), so it never goes on the stack.
+                const bool left_single = nl == 1, right_single = cnt - nl == 1;
+                const bool is_left = left_single && pos == a, is_right = right_single && pos == a + nl;
+                if (member && (is_left || is_right)) {
+                    const uint32_t cid = is_left ? child : child + 1;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        nd.box[6 * (size_t)cid + k] = lo[k];
+                        nd.box[6 * (size_t)cid + 3 + k] = hi[k];
+                        nd.zero[3 * (size_t)cid + k] = zinfo[k] ? ((pos * 3 + (zinfo[k] >> 1)) << 1) | (zinfo[k] & 1) : 0u;
+                    }
+                    nd.child[cid] = 0;
+                }
+                if (left_single || right_single) deepest = lev + 1 > deepest ? lev + 1 : deepest;
+                if (!right_single) {
+                    if (lane == sp) { st_range = (a + nl) | (b << 8) | ((lev + 1) << 16); st_id = child + 1; st_run = 0; }
+                    sp += 1;
+                }
+                if (!left_single) {
+                    if (lane == sp) { st_range = a | ((a + nl) << 8) | ((lev + 1) << 16); st_id = child; st_run = run + 1; }
+                    sp += 1;
+                }
             }
         }
         if (lane == 0) nd.child[id] = child;
