@@ -1329,9 +1329,10 @@ static int build_resident_attempt(const double *vertices, uint32_t n, uint32_t t
     for (uint32_t level = 0; !root_is_small; level++) {
         depth = (int)level;
         // While a level has only a few nodes every block's atomics meet at the same few
-        // addresses: then a block walks several tiles and sends one set per node.  Later
-        // one tile per block keeps more loads in flight.
-        const uint32_t tiles_per_block = (level_end - level_begin) < 8 ? std::min<uint32_t>(std::max<uint32_t>(tiles / 256, 1), 8) : 1;
+        // addresses: then a block walks two tiles and sends one set per node (more tiles per
+        // block leave CUs with uneven numbers of blocks, and the LDS atomics of the bin pass
+        // are what the level waits for).  Later one tile per block keeps more loads in flight.
+        const uint32_t tiles_per_block = ((level_end - level_begin) < 8 && tiles >= 512) ? 2 : 1;
         const uint32_t fat_blocks = blocks_for(tiles, tiles_per_block);
         hipLaunchKernelGGL(bounds_kernel, dim3(fat_blocks), dim3(kFat), 0, stream, T, idx[cur], node_of[cur], n, nd, tiles_per_block);
         const uint32_t width = level_end - level_begin;
