@@ -4,9 +4,9 @@ import numpy as np
 import ray_tracer_amd as rt
 rng = np.random.default_rng(2024)
 bad = 0
-for it in range(400):
+for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 400):
     n = int(rng.choice([1, 2, 3, 5, 8, 9, 33, 63, 64, 65, 66, 127, 128, 129, 200, 513, 1000, 3000, 7000]))
-    kind = it % 6
+    kind = it % 7
     if kind == 0:
         v = rng.uniform(-5, 5, size=(n, 1, 3)) + rng.uniform(-0.5, 0.5, size=(n, 3, 3))
     elif kind == 1:
@@ -21,6 +21,8 @@ for it in range(400):
     elif kind == 4:
         v = np.repeat(rng.uniform(-1, 1, size=(max(1, n // 7), 3, 3)), 7, axis=0)[:n]
         if v.shape[0] < n: v = np.concatenate([v, rng.uniform(-1, 1, size=(n - v.shape[0], 3, 3))])
+    elif kind == 6:      # coordinates so small that centroid differences are denormal or vanish
+        v = (rng.integers(-4, 5, size=(n, 3, 3)) * 2.0 ** float(rng.choice([-1074, -1070, -1040, -1022, -600]))).astype(np.float64)
     else:
         v = np.ones((n, 3, 3)); v[:, 1, 1] = 2; v[:, 2, 2] = 2
         v[:, 2, 0] += (rng.integers(0, 3, size=n)) * 2.0 ** -51
