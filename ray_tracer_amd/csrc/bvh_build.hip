@@ -330,8 +330,12 @@ __global__ __launch_bounds__(kFat) void bin_kernel(const TriRec *__restrict__ T,
                                                    uint32_t n, Nodes nd, Bins bins, uint32_t level_begin,
                                                    uint32_t tiles_per_block) {
     constexpr int kWaves = kFat / 64;
-    __shared__ unsigned long long s_lo[kWaves + 1][kBinSlots][3], s_hi[kWaves + 1][kBinSlots][3];   // [kWaves] = the block's
-    __shared__ uint32_t s_cnt[kWaves + 1][kBinSlots];
+    // Sets [0, kWaves): one per wave, for tiles that span several nodes.  Sets [kWaves, kWaves + kCopies): the block's, for
+    // tiles inside one node; lane l adds to copy l mod kCopies, so that the sixty-four atomics of one instruction meet at
+    // an address eight times less often (same-address LDS atomics run one after the other), merged when the node is sent.
+    constexpr int kCopies = 8;
+    __shared__ unsigned long long s_lo[kWaves + kCopies][kBinSlots][3], s_hi[kWaves + kCopies][kBinSlots][3];
+    __shared__ uint32_t s_cnt[kWaves + kCopies][kBinSlots];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     auto reset = [&](int which, int slot) {
         s_cnt[which][slot] = 0;
@@ -350,12 +354,22 @@ __global__ __launch_bounds__(kFat) void bin_kernel(const TriRec *__restrict__ T,
     auto flush = [&]() {
         __syncthreads();
         if (acc_node != kInactive && threadIdx.x < kBinSlots) {
-            send(kWaves, threadIdx.x, acc_node);
-            reset(kWaves, threadIdx.x);
+            const int slot = threadIdx.x;
+            for (int c = 1; c < kCopies; c++) {
+                s_cnt[kWaves][slot] += s_cnt[kWaves + c][slot];
+                for (int k = 0; k < 3; k++) {
+                    const unsigned long long l = s_lo[kWaves + c][slot][k], h = s_hi[kWaves + c][slot][k];
+                    if (l < s_lo[kWaves][slot][k]) s_lo[kWaves][slot][k] = l;
+                    if (h > s_hi[kWaves][slot][k]) s_hi[kWaves][slot][k] = h;
+                }
+            }
+            send(kWaves, slot, acc_node);
+            for (int c = 0; c < kCopies; c++) reset(kWaves + c, slot);
         }
         __syncthreads();
     };
-    if (threadIdx.x < kBinSlots) reset(kWaves, threadIdx.x);
+    if (threadIdx.x < kBinSlots)
+        for (int c = 0; c < kCopies; c++) reset(kWaves + c, threadIdx.x);
     __syncthreads();
     for (uint32_t tile = 0; tile < tiles_per_block; tile++) {
         const uint64_t start = ((uint64_t)blockIdx.x * tiles_per_block + tile) * kFat;
@@ -399,7 +413,7 @@ __global__ __launch_bounds__(kFat) void bin_kernel(const TriRec *__restrict__ T,
             }
         };
         if (uniform) {
-            if (node != kInactive) add_to(kWaves);
+            if (node != kInactive) add_to(kWaves + (lane & (kCopies - 1)));
             continue;
         }
         // runs of this wave, block-uniform number of rounds
