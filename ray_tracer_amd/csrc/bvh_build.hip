@@ -220,6 +220,14 @@ __device__ __forceinline__ uint32_t wave_max32(uint32_t v) {
     const uint32_t x = __builtin_amdgcn_readlane(v, 0), y = __builtin_amdgcn_readlane(v, 32);
     return x > y ? x : y;
 }
+// LDS traffic of one wave is executed in order; this keeps the compiler from moving
+// accesses across the point where other lanes' writes are consumed.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // updateNodeBounds (bvh.hpp:100-115) for every node of the new level at once, plus the
 // centroid bounds findBestSplitPlane starts with (bvh.hpp:242-250).
 // A block walks `tiles_per_block` consecutive tiles of kFat positions.  Tiles that lie
@@ -326,50 +334,51 @@ constexpr int kBinSlots = 3 * kBins;
 // node of the level.  Same tiling as bounds_kernel: tiles inside one node fill one set of
 // bins in LDS per block; in other tiles each wave accumulates every run of lanes that
 // share a node in its own LDS bins and adds the non-empty ones to the node's bins.
+// The CU's rate of 64-bit LDS atomics is what this pass waits for.
 __global__ __launch_bounds__(kFat) void bin_kernel(const TriRec *__restrict__ T, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ node_of,
                                                    uint32_t n, Nodes nd, Bins bins, uint32_t level_begin,
                                                    uint32_t tiles_per_block) {
     constexpr int kWaves = kFat / 64;
-    // Sets [0, kWaves): one per wave, for tiles that span several nodes.  Sets [kWaves, kWaves + kCopies): the block's, for
-    // tiles inside one node; lane l adds to copy l mod kCopies, so that the sixty-four atomics of one instruction meet at
-    // an address eight times less often (same-address LDS atomics run one after the other), merged when the node is sent.
-    constexpr int kCopies = 8;
-    __shared__ unsigned long long s_lo[kWaves + kCopies][kBinSlots][3], s_hi[kWaves + kCopies][kBinSlots][3];
-    __shared__ uint32_t s_cnt[kWaves + kCopies][kBinSlots];
+    // Same-address LDS atomics of one instruction run one after the other, so every set of bins exists in several
+    // copies and lane l adds to copy l mod (number of copies); the copies are merged when the set is sent.
+    // Sets [0, kWaves * kWaveCopies): kWaveCopies per wave, for tiles that span several nodes.
+    // Sets [kMine, kMine + kCopies): the block's, for tiles inside one node.
+    constexpr int kCopies = 8, kWaveCopies = 2, kMine = kWaves * kWaveCopies;
+    __shared__ unsigned long long s_lo[kMine + kCopies][kBinSlots][3], s_hi[kMine + kCopies][kBinSlots][3];
+    __shared__ uint32_t s_cnt[kMine + kCopies][kBinSlots];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     auto reset = [&](int which, int slot) {
         s_cnt[which][slot] = 0;
         for (int k = 0; k < 3; k++) { s_lo[which][slot][k] = kKeyMinInit; s_hi[which][slot][k] = kKeyMaxInit; }
     };
-    auto send = [&](int which, int slot, uint32_t node) {
-        if (!s_cnt[which][slot]) return;
-        const size_t w = (size_t)(node - level_begin) * kBinSlots + slot;
-        atomicAdd(bins.cnt + w, s_cnt[which][slot]);
-        for (int k = 0; k < 3; k++) {
-            atomicMin((unsigned long long *)bins.lo + 3 * w + k, s_lo[which][slot][k]);
-            atomicMax((unsigned long long *)bins.hi + 3 * w + k, s_hi[which][slot][k]);
+    // merges the `copies` sets that start at `first` into the first of them, adds it to the node's bins and clears them
+    auto send = [&](int first, int copies, int slot, uint32_t node) {
+        for (int c = 1; c < copies; c++) {
+            s_cnt[first][slot] += s_cnt[first + c][slot];
+            for (int k = 0; k < 3; k++) {
+                const unsigned long long l = s_lo[first + c][slot][k], h = s_hi[first + c][slot][k];
+                if (l < s_lo[first][slot][k]) s_lo[first][slot][k] = l;
+                if (h > s_hi[first][slot][k]) s_hi[first][slot][k] = h;
+            }
         }
+        if (s_cnt[first][slot]) {
+            const size_t w = (size_t)(node - level_begin) * kBinSlots + slot;
+            atomicAdd(bins.cnt + w, s_cnt[first][slot]);
+            for (int k = 0; k < 3; k++) {
+                atomicMin((unsigned long long *)bins.lo + 3 * w + k, s_lo[first][slot][k]);
+                atomicMax((unsigned long long *)bins.hi + 3 * w + k, s_hi[first][slot][k]);
+            }
+        }
+        for (int c = 0; c < copies; c++) reset(first + c, slot);
     };
     uint32_t acc_node = kInactive;                   // block-uniform
     auto flush = [&]() {
         __syncthreads();
-        if (acc_node != kInactive && threadIdx.x < kBinSlots) {
-            const int slot = threadIdx.x;
-            for (int c = 1; c < kCopies; c++) {
-                s_cnt[kWaves][slot] += s_cnt[kWaves + c][slot];
-                for (int k = 0; k < 3; k++) {
-                    const unsigned long long l = s_lo[kWaves + c][slot][k], h = s_hi[kWaves + c][slot][k];
-                    if (l < s_lo[kWaves][slot][k]) s_lo[kWaves][slot][k] = l;
-                    if (h > s_hi[kWaves][slot][k]) s_hi[kWaves][slot][k] = h;
-                }
-            }
-            send(kWaves, slot, acc_node);
-            for (int c = 0; c < kCopies; c++) reset(kWaves + c, slot);
-        }
+        if (acc_node != kInactive && threadIdx.x < kBinSlots) send(kMine, kCopies, threadIdx.x, acc_node);
         __syncthreads();
     };
     if (threadIdx.x < kBinSlots)
-        for (int c = 0; c < kCopies; c++) reset(kWaves + c, threadIdx.x);
+        for (int c = 0; c < kMine + kCopies; c++) reset(c, threadIdx.x);
     __syncthreads();
     for (uint32_t tile = 0; tile < tiles_per_block; tile++) {
         const uint64_t start = ((uint64_t)blockIdx.x * tiles_per_block + tile) * kFat;
@@ -413,20 +422,18 @@ __global__ __launch_bounds__(kFat) void bin_kernel(const TriRec *__restrict__ T,
             }
         };
         if (uniform) {
-            if (node != kInactive) add_to(kWaves + (lane & (kCopies - 1)));
+            if (node != kInactive) add_to(kMine + (lane & (kCopies - 1)));
             continue;
         }
-        // runs of this wave, block-uniform number of rounds
+        // the runs of this wave, one after the other; the wave's sets are its own, so it only waits for itself
         uint64_t todo = __ballot(node != kInactive);
-        while (__syncthreads_or(todo != 0)) {
-            uint32_t cur = kInactive;
-            if (todo) cur = __shfl(node, __ffsll((unsigned long long)todo) - 1);
-            const bool mine = todo && node == cur;
-            if (lane < kBinSlots) reset(wave, lane);
-            __syncthreads();
-            if (mine) add_to(wave);
-            __syncthreads();
-            if (todo && lane < kBinSlots) send(wave, lane, cur);
+        while (todo) {
+            const uint32_t cur = __shfl(node, __ffsll((unsigned long long)todo) - 1);
+            const bool mine = node == cur;
+            if (mine) add_to(wave * kWaveCopies + (lane & (kWaveCopies - 1)));
+            wave_sync();
+            if (lane < kBinSlots) send(wave * kWaveCopies, kWaveCopies, lane, cur);
+            wave_sync();
             todo &= ~__ballot(mine);
         }
     }
@@ -734,14 +741,6 @@ __device__ __forceinline__ uint32_t select_bit(uint64_t mask, uint32_t k) {
         if ((uint32_t)__popcll(mask & low_mask(pos + step)) < k) pos += step;
     return pos;
 }
-// LDS traffic of one wave is executed in order; this keeps the compiler from moving
-// accesses across the point where other lanes' writes are consumed.
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // subdivide (bvh.hpp:117-162) for every node below a small root, by one wave: lane = one
 // triangle of the root, which keeps its data in registers and only changes its position
 // `pos` inside the root's range when a partition moves it.  Pending nodes are kept in a
