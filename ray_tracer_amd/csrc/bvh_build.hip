@@ -335,7 +335,7 @@ constexpr int kBinSlots = 3 * kBins;
 // bins in LDS per block; in other tiles each wave accumulates every run of lanes that
 // share a node in its own LDS bins and adds the non-empty ones to the node's bins.
 // The CU's rate of 64-bit LDS atomics is what this pass waits for.
-__global__ __launch_bounds__(kFat) void bin_kernel(const TriRec *__restrict__ T, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ node_of,
+__global__ __launch_bounds__(kFat, 8) void bin_kernel(const TriRec *__restrict__ T, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ node_of,
                                                    uint32_t n, Nodes nd, Bins bins, uint32_t level_begin,
                                                    uint32_t tiles_per_block) {
     constexpr int kWaves = kFat / 64;
