@@ -1188,7 +1188,7 @@ hipError_t upload_pageable(void *dst, const void *src, size_t bytes, hipStream_t
         return e == hipSuccess ? hipStreamSynchronize(stream) : e;
     }
     // One host thread fills pinned memory slower than the link drains it: kThreads of them take the pieces in turn, each
-    // with two pinned buffers and a stream of its own, so that filling one buffer overlaps the DMA of the other.
+    // with two pinned buffers, so that filling one buffer overlaps the DMA of the other.
     static std::mutex turn;
     static void *ring[kThreads][kRing] = {};        // pinned, visible to every device; kept until the process ends
     std::lock_guard<std::mutex> hold(turn);
@@ -1201,22 +1201,17 @@ hipError_t upload_pageable(void *dst, const void *src, size_t bytes, hipStream_t
     int device = 0;
     e = hipGetDevice(&device);
     if (e != hipSuccess) return e;
-    // streams and events are made once per device and kept: creating one takes the runtime's lock, which would hold up
-    // the kernel launches of whoever builds a tree meanwhile
-    struct Lanes { hipStream_t s[kThreads] = {}; hipEvent_t landed[kThreads][kRing] = {}; };
+    // Every piece goes down the caller's stream (one stream already runs the link at its rate; streams of the library's
+    // own would take hardware queues away from the caller's).  The events are made once per device and kept.
+    struct Lanes { hipEvent_t landed[kThreads][kRing] = {}; };
     static std::map<int, Lanes> per_device;
     Lanes &lanes = per_device[device];
-    for (int t = 0; t < kThreads; t++) {
-        if (!lanes.s[t]) {
-            e = hipStreamCreateWithFlags(&lanes.s[t], hipStreamNonBlocking);
-            if (e != hipSuccess) { lanes.s[t] = nullptr; return e; }
-        }
+    for (int t = 0; t < kThreads; t++)
         for (int k = 0; k < kRing; k++)
             if (!lanes.landed[t][k]) {
                 e = hipEventCreateWithFlags(&lanes.landed[t][k], hipEventDisableTiming);
                 if (e != hipSuccess) { lanes.landed[t][k] = nullptr; return e; }
             }
-    }
     const size_t n_pieces = (bytes + kPiece - 1) / kPiece;
     hipError_t result[kThreads];
     auto work = [&](int t) {
@@ -1228,19 +1223,20 @@ hipError_t upload_pageable(void *dst, const void *src, size_t bytes, hipStream_t
             if (round >= (size_t)kRing) r = hipEventSynchronize(lanes.landed[t][k]);     // the buffer's previous piece has left it
             if (r != hipSuccess) break;
             memcpy(ring[t][k], static_cast<const char *>(src) + off, len);
-            r = hipMemcpyAsync(static_cast<char *>(dst) + off, ring[t][k], len, hipMemcpyHostToDevice, lanes.s[t]);
-            if (r == hipSuccess) r = hipEventRecord(lanes.landed[t][k], lanes.s[t]);
+            r = hipMemcpyAsync(static_cast<char *>(dst) + off, ring[t][k], len, hipMemcpyHostToDevice, stream);
+            // recorded after this thread's copy whatever the other threads queue in between
+            if (r == hipSuccess) r = hipEventRecord(lanes.landed[t][k], stream);
         }
-        // the buffers are the next caller's: every piece must have left them before the turn ends
-        const hipError_t drained = hipStreamSynchronize(lanes.s[t]);
-        result[t] = r == hipSuccess ? drained : r;
+        result[t] = r;
     };
     std::thread helpers[kThreads - 1];
     for (int t = 1; t < kThreads; t++) helpers[t - 1] = std::thread(work, t);
     work(0);
     for (std::thread &h : helpers) h.join();
+    // the buffers are the next caller's: every piece must have left them before the turn ends
+    const hipError_t drained = hipStreamSynchronize(stream);
     for (int t = 0; t < kThreads; t++) if (result[t] != hipSuccess) return result[t];
-    return hipSuccess;
+    return drained;
 }
 
 // One attempt with room for `top_cap` nodes in the level passes (nodes of more than kSmall triangles and their
