@@ -134,8 +134,11 @@ def main():
 
     if args.inflight is None:
         args.inflight = 8 if int(os.environ.get("WORLD_SIZE", "1")) >= 8 else 4       # measured: tools/shard_time.py
-    if args.inflight > 4:
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")       # read by the HIP runtime when it starts; 4 is its default
+    if args.inflight > 4 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # Read by the HIP runtime when it starts; 4 is its default.  Frames in flight overlap only while their streams sit on
+        # different hardware queues, and a process's live streams share the queues in turn: with RCCL's own streams in the
+        # process, four queues no longer keep four frames apart (eight queues with four frames measure the same as four).
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     # Libraries (gloo, RCCL, the HIP runtime) print notices on file descriptor 1; the one JSON line must be all that
     # reaches standard output, so everything else is sent to standard error and the line is written to the saved descriptor.
