@@ -1,6 +1,6 @@
 """The drop-in carried out inside the reference's own program: oracle/_ref/ref_dropin is the reference's Scene
-factory, loader and BVH constructor (its headers, compiled in the build container), the binding code printed in
-INTEGRATION.md, one rtx_render() call in place of the thread fan-out, and the reference's own per-pixel loop run
+factory, loader and BVH constructor (its headers, compiled in the build container), the binding code a maintainer
+would add (scene arrays handed to rtx_scene_create), one rtx_render() call in place of the thread fan-out, and the reference's own per-pixel loop run
 beside it on host threads; it exits 0 when every primary triangle id and every colour agree."""
 import os
 import shutil
