@@ -1196,7 +1196,13 @@ hipError_t upload_pageable(void *dst, const void *src, size_t bytes, hipStream_t
         for (int k = 0; k < kRing; k++)
             if (!ring[t][k]) {
                 e = hipHostMalloc(&ring[t][k], kPiece, hipHostMallocPortable);
-                if (e != hipSuccess) { ring[t][k] = nullptr; return e; }
+                if (e != hipSuccess) {
+                    // no pinned memory to be had: the runtime's own path for pageable memory, at half the rate
+                    ring[t][k] = nullptr;
+                    (void)hipGetLastError();
+                    e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
+                    return e == hipSuccess ? hipStreamSynchronize(stream) : e;
+                }
             }
     int device = 0;
     e = hipGetDevice(&device);
