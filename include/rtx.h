@@ -285,12 +285,13 @@ int rtx_render_device(rtx_scene *scene, const rtx_render_params *p, void *d_rgb_
 int rtx_render_device_timed(rtx_scene *scene, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id,
                             void *d_rgb_i32, void *d_t, void *d_stats, void *d_ticks, void *stream);
 
-/* rtx_render_device() for callers that cannot allocate: code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same arguments, same
+/* rtx_render_device() for callers that cannot allocate: tight serving loops, harnesses that forbid
+ * hipMalloc, code that records its stream.  No counterpart in the reference.  Same arguments, same
  * frame, bit for bit; but the launch's scratch (work counters, work-queue table, per-lane shading
  * state) lives in a 32 MiB array that is part of the library's device code, one copy per GPU for
  * the life of the process, and the call makes no hipMalloc / hipFree / event or stream creation
- * (only a memset and two kernel launches on `stream`).
+ * and no synchronisation: two kernel launches on `stream`, nothing else.  (Tested as launched
+ * directly; replaying the two launches from a recorded HIP graph is not covered by a test.)
  * Limits: a frame whose work-queue table (4 bytes per owned tile + 4 per 8x8 group of tiles) does
  * not leave room for one block's lanes is refused with RTX_ERR_UNSUPPORTED -- about 8 million
  * tiles; at 32x32-pixel tiles no canvas this library accepts comes near -- and a launch that

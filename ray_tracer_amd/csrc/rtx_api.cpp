@@ -841,7 +841,7 @@ static int render_device_timed_impl(rtx_scene *sc, const rtx_render_params *p, v
     // another geometry (or a smaller lane count, which moves nothing: the table sits in front) uses it.
     const std::vector<int64_t> key = {r.W, r.H, r.tile_w, r.tile_h, r.tile_rank, r.tile_count, plan.n_queues, plan.macro, plan.centre_first};
     if (key != sc->slot_key[slot]) {
-        HIP_TRY(rtx::launch_tile_order((uint32_t *)r.tile_order, r, plan.macro, plan.n_queues, plan.centre_first, st));
+        HIP_TRY(rtx::launch_tile_order((uint32_t *)r.tile_order, r, plan.macro, plan.n_queues, plan.centre_first, false, st));
         sc->slot_key[slot] = key;
     }
     // Diagnostics: RTX_WAVE_LOG=<file> records every wave's start/end tick (100 MHz) of this
@@ -890,8 +890,8 @@ static int render_device_noalloc_impl(rtx_scene *sc, const rtx_render_params *p,
                                          "work-queue table holds (32 MiB in all; use larger tiles or rtx_render_device)");
     plan.grid_blocks = std::min<uint64_t>(plan.grid_blocks, (rtx::kNoallocScratchBytes - fixed) / per_block);
     bind_scratch(&plan, base);
-    HIP_TRY(hipMemsetAsync(r.work, 0, rtx::kScratchHeaderBytes, st));       // the last call's counters
-    HIP_TRY(rtx::launch_tile_order((uint32_t *)r.tile_order, r, plan.macro, plan.n_queues, plan.centre_first, st));
+    // two kernels and nothing else on the stream: the first one clears the last call's counters and writes the table
+    HIP_TRY(rtx::launch_tile_order((uint32_t *)r.tile_order, r, plan.macro, plan.n_queues, plan.centre_first, true, st));
     HIP_TRY(rtx::launch_render(sc->dev, r, plan.pruned, d_stats != nullptr, plan.block, (uint32_t)plan.grid_blocks, st));
     return RTX_OK;
 }

@@ -49,7 +49,9 @@ constexpr uint64_t kNoallocScratchBytes = 32ull << 20;
 hipError_t noalloc_scratch(int device, void **ptr);
 
 // Builds the work-queue table of `rp` at d_order (render_order_words() words) on the stream.
-hipError_t launch_tile_order(uint32_t *d_order, const DevRender &rp, int macro, int n_queues, int centre_first, hipStream_t st);
+// clear_counters: the kernel also zeroes the launch's work counters (rp.work, kScratchHeaderBytes), in place of a memset.
+hipError_t launch_tile_order(uint32_t *d_order, const DevRender &rp, int macro, int n_queues, int centre_first, bool clear_counters,
+                             hipStream_t st);
 
 // 256-thread blocks of the render kernel one CU keeps resident (= its waves per SIMD)
 int render_blocks_per_cu();

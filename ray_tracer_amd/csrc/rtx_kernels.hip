@@ -783,7 +783,10 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
                     for (uint32_t k = 0; k < rp.n_queues && drained; k++) {
                         const uint32_t q = (home_queue + k) % rp.n_queues;
                         if (exhausted & (1u << q)) continue;
-                        const uint32_t q_begin = rp.tile_order[q], q_tiles = rp.tile_order[q + 1] - q_begin;
+                        const uint32_t q_begin = rp.tile_order[q], q_end = rp.tile_order[q + 1], q_tiles = q_end - q_begin;
+                        // a table that is not one (a caller broke the ordering of the launches that share it) must not
+                        // become an address: the queue then counts as empty
+                        if (q_end < q_begin || q_end > (uint32_t)rp.owned_tiles) { exhausted |= 1u << q; continue; }
                         uint32_t i = 0;
                         if (lane == 0) i = atomicAdd(rp.work + q * 32u, 1u);
                         i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
@@ -919,7 +922,10 @@ __global__ void __launch_bounds__(64) top_table_kernel(const DevNode *nodes, Dev
 // tile, one thread per queue turns the counts into offsets, then every macro tile writes its tiles.
 // `order` has room for 9 + owned tiles + 2 x macro tiles words (counts and serving order live behind the table).
 __global__ void __launch_bounds__(1024) tile_order_kernel(uint32_t *order, int tiles_x, int tiles_y, int tile_rank, int tile_count,
-                                                          uint32_t owned, int macro, int n_queues, int centre_first) {
+                                                          uint32_t owned, int macro, int n_queues, int centre_first,
+                                                          uint32_t *clear, uint32_t n_clear) {
+    // `clear` (nullable): the launch's work counters, zeroed here for a caller that wants kernels only on its stream
+    for (uint32_t i = threadIdx.x; i < n_clear; i += blockDim.x) clear[i] = 0u;
     const int macros_x = (tiles_x + macro - 1) / macro, macros_y = (tiles_y + macro - 1) / macro;
     const int n_macros = macros_x * macros_y;
     uint32_t *cnt = order + 9u + owned;          // per macro tile: its tiles, then its offset inside its queue
@@ -1026,9 +1032,11 @@ hipError_t launch_top_table(const DevNode *d_nodes, DevNode *d_top, uint32_t max
     return hipGetLastError();
 }
 
-hipError_t launch_tile_order(uint32_t *d_order, const DevRender &rp, int macro, int n_queues, int centre_first, hipStream_t st) {
+hipError_t launch_tile_order(uint32_t *d_order, const DevRender &rp, int macro, int n_queues, int centre_first, bool clear_counters,
+                             hipStream_t st) {
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, d_order, rp.tiles_x, rp.tiles_y, rp.tile_rank, rp.tile_count,
-                       (uint32_t)rp.owned_tiles, macro, n_queues, centre_first);
+                       (uint32_t)rp.owned_tiles, macro, n_queues, centre_first, clear_counters ? rp.work : nullptr,
+                       clear_counters ? (uint32_t)(kScratchHeaderBytes / 4) : 0u);
     return hipGetLastError();
 }
 
