@@ -233,7 +233,7 @@ __device__ __forceinline__ void wave_sync() {
 // A block walks `tiles_per_block` consecutive tiles of kFat positions.  Tiles that lie
 // inside one node are accumulated in LDS across tiles, so that a large node receives one
 // set of atomics per block; other tiles send one set per run of lanes that share a node.
-__global__ __launch_bounds__(kFat) void bounds_kernel(const TriRec *__restrict__ T, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ node_of,
+__global__ __launch_bounds__(kFat, 8) void bounds_kernel(const TriRec *__restrict__ T, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ node_of,
                                                       uint32_t n, Nodes nd, uint32_t tiles_per_block) {
     // 0-2 bmin, 3-5 bmax, 6-8 centroid min, 9-11 centroid max, 12-14 zero trackers
     __shared__ unsigned long long s_acc[15];
@@ -266,56 +266,44 @@ __global__ __launch_bounds__(kFat) void bounds_kernel(const TriRec *__restrict__
             flush();
             acc_node = uniform ? tile_node : kInactive;
         }
-        uint64_t lo[3], hi[3], clo[3], chi[3], zs[3];
-        if (node != kInactive) {
-            const TriRec r = load_tri(T, idx[p]);
+        const bool act = node != kInactive;
+        TriRec r;
+        if (act) r = load_tri(T, idx[p]);
+        // One axis at a time, reduced and sent before the next one is touched: fewer values live at once, so the kernel
+        // fits 64 registers and two blocks share a CU (the pass waits for its gathers, not for arithmetic).
+        const uint32_t next = __shfl_down(node, 1);
+        const bool tail = uniform ? (lane == 0 && __ballot(node != kInactive) != 0)
+                                  : ((lane == 63 || next != node) && node != kInactive);
+        unsigned long long *box = uniform ? s_acc : (unsigned long long *)nd.box + 6 * (size_t)(tail ? node : 0);
+        unsigned long long *cbox = uniform ? s_acc + 6 : (unsigned long long *)nd.cbox + 6 * (size_t)(tail ? node : 0);
+        unsigned long long *zero = uniform ? s_acc + 12 : (unsigned long long *)nd.zero + 3 * (size_t)(tail ? node : 0);
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                lo[k] = r.lo[k];
-                hi[k] = r.hi[k];
-                zs[k] = zero_key(r.zeros, k, p);
-                clo[k] = chi[k] = key_of(r.c[k]);
+        for (int k = 0; k < 3; k++) {
+            // lanes without a triangle hold the neutral values
+            uint64_t l = act ? r.lo[k] : kKeyMinInit, h = act ? r.hi[k] : kKeyMaxInit;
+            uint64_t cl = act ? key_of(r.c[k]) : kKeyMinInit, ch = act ? key_of(r.c[k]) : kKeyMaxInit;
+            uint64_t z = act ? zero_key(r.zeros, k, p) : 0ull;
+            if (uniform) {
+                // every lane of the tile (bar the ones past the end, which hold the neutral values) belongs to one node:
+                // plain wave reductions, no segment bookkeeping and no trips through the LDS crossbar
+                l = wave_reduce64<true>(l);
+                h = wave_reduce64<false>(h);
+                cl = wave_reduce64<true>(cl);
+                ch = wave_reduce64<false>(ch);
+                z = wave_reduce64<false>(z);
+            } else {
+                l = run_reduce<true>(l, node, lane);
+                h = run_reduce<false>(h, node, lane);
+                cl = run_reduce<true>(cl, node, lane);
+                ch = run_reduce<false>(ch, node, lane);
+                z = run_reduce<false>(z, node, lane);
             }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 3; k++) { lo[k] = clo[k] = kKeyMinInit; hi[k] = chi[k] = kKeyMaxInit; zs[k] = 0; }
-        }
-        bool tail;
-        if (uniform) {
-            // every lane of the tile (bar the ones past the end, which hold the neutral values) belongs to one node: plain
-            // wave reductions, no segment bookkeeping and no trips through the LDS crossbar
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                lo[k] = wave_reduce64<true>(lo[k]);
-                hi[k] = wave_reduce64<false>(hi[k]);
-                clo[k] = wave_reduce64<true>(clo[k]);
-                chi[k] = wave_reduce64<false>(chi[k]);
-                zs[k] = wave_reduce64<false>(zs[k]);
-            }
-            tail = lane == 0 && __ballot(node != kInactive) != 0;
-        } else {
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                lo[k] = run_reduce<true>(lo[k], node, lane);
-                hi[k] = run_reduce<false>(hi[k], node, lane);
-                clo[k] = run_reduce<true>(clo[k], node, lane);
-                chi[k] = run_reduce<false>(chi[k], node, lane);
-                zs[k] = run_reduce<false>(zs[k], node, lane);
-            }
-            const uint32_t next = __shfl_down(node, 1);
-            tail = (lane == 63 || next != node) && node != kInactive;
-        }
-        if (tail) {
-            unsigned long long *box = uniform ? s_acc : (unsigned long long *)nd.box + 6 * (size_t)node;
-            unsigned long long *cbox = uniform ? s_acc + 6 : (unsigned long long *)nd.cbox + 6 * (size_t)node;
-            unsigned long long *zero = uniform ? s_acc + 12 : (unsigned long long *)nd.zero + 3 * (size_t)node;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                atomicMin(box + k, (unsigned long long)lo[k]);
-                atomicMax(box + 3 + k, (unsigned long long)hi[k]);
-                atomicMin(cbox + k, (unsigned long long)clo[k]);
-                atomicMax(cbox + 3 + k, (unsigned long long)chi[k]);
-                if (zs[k]) atomicMax(zero + k, (unsigned long long)zs[k]);
+            if (tail) {
+                atomicMin(box + k, (unsigned long long)l);
+                atomicMax(box + 3 + k, (unsigned long long)h);
+                atomicMin(cbox + k, (unsigned long long)cl);
+                atomicMax(cbox + 3 + k, (unsigned long long)ch);
+                if (z) atomicMax(zero + k, (unsigned long long)z);
             }
         }
     }
