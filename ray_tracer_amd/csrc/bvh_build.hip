@@ -318,6 +318,13 @@ struct Bins {
 };
 constexpr int kBinSlots = 3 * kBins;
 
+// Empty bins for the `width` nodes of a level (one launch in place of three fills).
+__global__ void bins_clear_kernel(Bins bins, uint32_t width) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x, slots = (uint64_t)width * kBinSlots;
+    if (i < slots * 3) { bins.lo[i] = kKeyMinInit; bins.hi[i] = kKeyMaxInit; }
+    if (i < slots) bins.cnt[i] = 0;
+}
+
 // The binning loop of findBestSplitPlane (bvh.hpp:259-266) for all three axes of every
 // node of the level.  Same tiling as bounds_kernel: tiles inside one node fill one set of
 // bins in LDS per block; in other tiles each wave accumulates every run of lanes that
@@ -1345,9 +1352,7 @@ static int build_resident_attempt(const double *vertices, uint32_t n, uint32_t t
             HIP_TRY_B(buf.get(&bins.hi, bins_width * kBinSlots * 3));
             HIP_TRY_B(buf.get(&bins.cnt, bins_width * kBinSlots));
         }
-        HIP_TRY_B(hipMemsetAsync(bins.lo, 0xff, (size_t)width * kBinSlots * 3 * sizeof(uint64_t), stream));
-        HIP_TRY_B(hipMemsetAsync(bins.hi, 0x00, (size_t)width * kBinSlots * 3 * sizeof(uint64_t), stream));
-        HIP_TRY_B(hipMemsetAsync(bins.cnt, 0x00, (size_t)width * kBinSlots * sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(bins_clear_kernel, dim3(blocks_for((uint64_t)width * kBinSlots * 3)), dim3(kBlock), 0, stream, bins, width);
         const uint32_t node_blocks = blocks_for(width);
         hipLaunchKernelGGL(bin_kernel, dim3(fat_blocks), dim3(kFat), 0, stream, T, idx[cur], node_of[cur], n, nd, bins, level_begin,
                            tiles_per_block);
