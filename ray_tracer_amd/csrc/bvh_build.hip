@@ -741,7 +741,7 @@ __device__ __forceinline__ uint32_t select_bit(uint64_t mask, uint32_t k) {
 // `pos` inside the root's range when a partition moves it.  Pending nodes are kept in a
 // stack spread over the lanes' registers.  Node ids come from a block of 2m-2 ids reserved
 // for the root; ids left over are marked unused.
-__global__ __launch_bounds__(kBlock) void subtree_kernel(const TriRec *__restrict__ T,
+__global__ __launch_bounds__(kBlock, 5) void subtree_kernel(const TriRec *__restrict__ T,
                                                          uint32_t *__restrict__ idx, const uint2 *__restrict__ small_list,
                                                          const uint32_t *__restrict__ need_local,
                                                          const uint32_t *__restrict__ need_sums, uint32_t n_small,

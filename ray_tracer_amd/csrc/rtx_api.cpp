@@ -972,15 +972,18 @@ static int render_begin_impl(rtx_scene *sc, const rtx_render_params *p, int32_t 
     h.pixels = px;
     h.want_hit = want_hit_ids != 0;
     h.busy = true;
-    if (px == 0) return RTX_OK;
+    // a failure below leaves the slot free again
+    struct Release { rtx_scene::HostSlot &h; bool keep = false; ~Release() { if (!keep) h.busy = false; } } release{h};
+    if (px == 0) { release.keep = true; return RTX_OK; }
     HIP_TRY(grow_pair(&h.d_rgb, &h.h_rgb, &h.rgb_bytes, px * 3));
     if (h.want_hit) HIP_TRY(grow_pair(&h.d_hit, &h.h_hit, &h.hit_bytes, px * 4));
     // pixels outside the window (and the padding of packed tiles) read 0 / -1
     HIP_TRY(hipMemsetAsync(h.d_rgb, 0, px * 3, h.stream));
     if (h.want_hit) HIP_TRY(hipMemsetAsync(h.d_hit, 0xff, px * 4, h.stream));
-    if (int rc = rtx_render_device(sc, p, h.d_rgb, h.want_hit ? h.d_hit : nullptr, nullptr, nullptr, nullptr, h.stream)) { h.busy = false; return rc; }
+    if (int rc = rtx_render_device(sc, p, h.d_rgb, h.want_hit ? h.d_hit : nullptr, nullptr, nullptr, nullptr, h.stream)) return rc;
     HIP_TRY(hipMemcpyAsync(h.h_rgb, h.d_rgb, px * 3, hipMemcpyDeviceToHost, h.stream));
     if (h.want_hit) HIP_TRY(hipMemcpyAsync(h.h_hit, h.d_hit, px * 4, hipMemcpyDeviceToHost, h.stream));
+    release.keep = true;
     return RTX_OK;
 }
 
