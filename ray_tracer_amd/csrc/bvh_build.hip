@@ -166,6 +166,11 @@ __device__ __forceinline__ uint64_t shfl_up64(uint64_t v, int d) {
     return ((uint64_t)hi << 32) | lo;
 }
 
+__device__ __forceinline__ double shfl_f64(double v, int src) {
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = __shfl((uint32_t)b, src), hi = __shfl((uint32_t)(b >> 32), src);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
 // Reduction over runs of equal `node` among consecutive lanes; the last lane of a run
 // ends up with the run's result.
 template <bool IS_MIN>
@@ -442,16 +447,19 @@ __device__ __forceinline__ double half_area(const double lo[3], const double hi[
 }
 
 // findBestSplitPlane's plane sweep (bvh.hpp:268-302) and subdivide's cost test
-// (bvh.hpp:117-126), one thread per node of the level.
+// (bvh.hpp:117-126): four lanes per node of the level, three of them sweep one axis each, the first
+// one then takes the axes' results in the reference's order (a later axis wins only with a smaller cost).
 __global__ void plane_kernel(Nodes nd, Bins bins, uint32_t level_begin, uint32_t level_end) {
-    const uint32_t t = level_begin + blockIdx.x * kBlock + threadIdx.x;
-    if (t >= level_end || nd.count[t] <= kSmall) return;
+    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t t = level_begin + (g >> 2);
+    const int a = (int)(g & 3u);
+    if (t >= level_end || nd.count[t] <= kSmall) return;          // the four lanes of a node leave together
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
     double best = inf, best_pos = 0;
     int best_axis = -1;
-    for (int a = 0; a < 3; a++) {
+    if (a < 3) {
         const double cmin = value_of(nd.cbox[6 * (size_t)t + a]), cmax = value_of(nd.cbox[6 * (size_t)t + 3 + a]);
-        if (cmin == cmax) continue;
+        if (cmin != cmax) {
         const size_t w = ((size_t)(t - level_begin) * 3 + a) * kBins;
         double blo[kBins][3], bhi[kBins][3];
         int bcount[kBins];
@@ -493,7 +501,15 @@ __global__ void plane_kernel(Nodes nd, Bins bins, uint32_t level_begin, uint32_t
                 best_pos = cmin + width * static_cast<double>(i + 1);
             }
         }
+        }
     }
+    // axes 1 and 2 hand their best to the node's first lane
+    for (int from = 1; from < 3; from++) {
+        const int src = (int)(threadIdx.x & 63u) - a + from;
+        const double c = shfl_f64(best, src), ps = shfl_f64(best_pos, src);
+        if (a == 0 && c < best) { best = c; best_pos = ps; best_axis = from; }
+    }
+    if (a != 0) return;
     double lo[3], hi[3];
     for (int k = 0; k < 3; k++) { lo[k] = value_of(nd.box[6 * (size_t)t + k]); hi[k] = value_of(nd.box[6 * (size_t)t + 3 + k]); }
     const double parent_cost = static_cast<double>(nd.count[t]) * half_area(lo, hi);   // BVHNode::cost, bvh.hpp:80-82
@@ -721,11 +737,6 @@ __device__ __forceinline__ void wave_argmin(double &cost, int &tag) {
     cost = __longlong_as_double((long long)c0);
     tag = (int)t0;
     step(c1, t1);
-}
-__device__ __forceinline__ double shfl_f64(double v, int src) {
-    const uint64_t b = (uint64_t)__double_as_longlong(v);
-    const uint32_t lo = __shfl((uint32_t)b, src), hi = __shfl((uint32_t)(b >> 32), src);
-    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 __device__ __forceinline__ uint64_t low_mask(uint32_t k) { return k >= 64 ? ~0ull : ((1ull << k) - 1); }
 // Position of the k-th set bit (k >= 1, counted from bit 0) of a mask that has one.
@@ -1356,7 +1367,7 @@ static int build_resident_attempt(const double *vertices, uint32_t n, uint32_t t
         const uint32_t node_blocks = blocks_for(width);
         hipLaunchKernelGGL(bin_kernel, dim3(fat_blocks), dim3(kFat), 0, stream, T, idx[cur], node_of[cur], n, nd, bins, level_begin,
                            tiles_per_block);
-        hipLaunchKernelGGL(plane_kernel, dim3(node_blocks), dim3(kBlock), 0, stream, nd, bins, level_begin, level_end);
+        hipLaunchKernelGGL(plane_kernel, dim3(blocks_for((uint64_t)width * 4)), dim3(kBlock), 0, stream, nd, bins, level_begin, level_end);
         hipLaunchKernelGGL(flag_kernel, dim3(chunks), dim3(kBlock), 0, stream, T, idx[cur], node_of[cur], n, nd, flag, local, sums);
         hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, stream, sums, chunks);
         hipLaunchKernelGGL(split_kernel, dim3(node_blocks), dim3(kBlock), 0, stream, nd, pre, flag, level_begin, level_end, counters,
