@@ -264,7 +264,7 @@ def main():
         elapsed = float(tt.item())
     event_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
     tk = ticks.cpu().numpy().astype("uint64").reshape(-1, 2)
-    kernel_ms = float(((tk[:, 1] - tk[:, 0]).astype("float64") * 1e-5).mean())      # 100 MHz ticks -> ms
+    kernel_ms = float(((tk[:, 1] - ~tk[:, 0]).astype("float64") * 1e-5).mean())     # [0] holds the complement of the start; 100 MHz ticks -> ms
     frame_crc = None
     if rank == 0:
         import zlib

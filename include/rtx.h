@@ -279,19 +279,22 @@ int rtx_render_device(rtx_scene *scene, const rtx_render_params *p, void *d_rgb_
                       void *d_rgb_i32, void *d_t, void *d_stats, void *stream);
 
 /* The same launch, which also leaves its own duration on the device: d_ticks (nullable)
- * points to two uint64 that receive the start of the first and the end of the last block of
- * the render kernel on the device's 100 MHz clock.  With several frames in flight, events on
+ * points to two uint64 that the CALLER HAS ZEROED (the call adds no clearing dispatch in front
+ * of the frame); when the launch is over, d_ticks[0] holds the bitwise complement of the start of
+ * the first block and d_ticks[1] the end of the last block of the render kernel on the device's
+ * 100 MHz clock: duration = d_ticks[1] - ~d_ticks[0].  With several frames in flight, events on
  * a stream also count the wait for the chip; this does not.  No counterpart in the reference. */
 int rtx_render_device_timed(rtx_scene *scene, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id,
                             void *d_rgb_i32, void *d_t, void *d_stats, void *d_ticks, void *stream);
 
 /* rtx_render_device() for callers that cannot allocate: tight serving loops, harnesses that forbid
- * hipMalloc, code that records its stream.  No counterpart in the reference.  Same arguments, same
+ * hipMalloc.  No counterpart in the reference.  Same arguments, same
  * frame, bit for bit; but the launch's scratch (work counters, work-queue table, per-lane shading
  * state) lives in a 32 MiB array that is part of the library's device code, one copy per GPU for
  * the life of the process, and the call makes no hipMalloc / hipFree / event or stream creation
- * and no synchronisation: two kernel launches on `stream`, nothing else.  (Tested as launched
- * directly; replaying the two launches from a recorded HIP graph is not covered by a test.)
+ * and no synchronisation: two kernel launches on `stream`, nothing else.  A stream that is
+ * being captured into a HIP graph is refused (RTX_ERR_UNSUPPORTED): replay of the two launches is
+ * not verified.
  * Limits: a frame whose work-queue table (4 bytes per owned tile + 4 per 8x8 group of tiles) does
  * not leave room for one block's lanes is refused with RTX_ERR_UNSUPPORTED -- about 8 million
  * tiles; at 32x32-pixel tiles no canvas this library accepts comes near -- and a launch that
@@ -328,13 +331,37 @@ int32_t rtx_scene_group_size(const rtx_scene_group *group);
 int32_t rtx_scene_group_device(const rtx_scene_group *group, int32_t i);
 rtx_scene *rtx_scene_group_scene(rtx_scene_group *group, int32_t i);
 
+/* How the members' packed tile buffers come together.  RTX_GATHER_ALL (the default): one ncclAllGather, every
+ * member ends with the whole frame's tiles.  RTX_GATHER_ROOT: ncclSend from every other member, ncclRecv on the
+ * root: only the root needs the frame, and 1/N of the all-gather's bytes cross the links.  The environment
+ * variable RTX_GROUP_GATHER=all|root sets a new group's mode. */
+#define RTX_GATHER_ALL 0
+#define RTX_GATHER_ROOT 1
+int rtx_scene_group_set_gather(rtx_scene_group *group, int32_t mode);
+
+/* The exchange as a list of operations, which is what the group executes (exposed so that the plan can be
+ * checked without a second GPU): member `member` runs operation `kind` -- an all-gather of its `bytes`, a send of
+ * `bytes` at src_offset of its packed buffer to member `peer`, a receive of `bytes` from `peer` at dst_offset
+ * of its gathered buffer, or a local copy from src_offset of its packed buffer to dst_offset of its gathered
+ * buffer.  Returns the number of operations written (at most 2 n_members), or a negative rtx_status. */
+typedef struct rtx_gather_op {
+    int32_t kind, member, peer, reserved;
+    uint64_t src_offset, dst_offset, bytes;
+} rtx_gather_op;
+#define RTX_GATHER_OP_ALLGATHER 0
+#define RTX_GATHER_OP_SEND 1
+#define RTX_GATHER_OP_RECV 2
+#define RTX_GATHER_OP_COPY 3
+int32_t rtx_gather_plan(int32_t n_members, uint64_t local_bytes, int32_t mode, rtx_gather_op *ops, int32_t max_ops);
+
 /* One frame into a HOST buffer (3 bytes per pixel, row-major), rendered by all members; replaces
  * the fan-out and join of src/main.cpp:45-52.  p->tile_rank, tile_count and layout are set by the
  * call; hit ids and counters are not gathered (render one member's scene for those). */
 int rtx_render_sharded(rtx_scene_group *group, const rtx_render_params *p, uint8_t *rgb_out);
 
 /* The same frame left on the root device, asynchronously: the work is queued on frame slot `slot`
- * (0..3, each with its own streams and buffers, so up to four frames overlap) and *d_rgb_u8
+ * (0..3, each with its own render streams and buffers, so up to four frames overlap; the
+ * exchanges of all slots share one high-priority stream per member) and *d_rgb_u8
  * receives the root-device pointer of that slot's frame, complete after rtx_scene_group_sync().
  * A slot's next frame is ordered behind its previous one. */
 int rtx_render_sharded_device(rtx_scene_group *group, const rtx_render_params *p, int32_t slot, void **d_rgb_u8);

@@ -28,6 +28,8 @@
 #include <string>
 #include <vector>
 
+#include <unistd.h>
+
 #include "rtx.h"
 
 namespace rtx_reference_api_detail {
@@ -64,7 +66,17 @@ struct Scene {
         if (n_gpus == 1) {
             if (rtx_scene_create_from_host(h->host, -1, &h->device) != RTX_OK) throw rtx_last_error();
         } else {
-            if (rtx_scene_group_create_from_host(h->host, nullptr, n_gpus, &h->group) != RTX_OK) throw rtx_last_error();
+            /* RCCL may announce its version on standard output while its communicators are created.  This driver's
+             * standard output carries the reference's lines and nothing else, so for that one call -- made before any
+             * other thread of the driver exists -- descriptor 1 points at standard error. */
+            fflush(stdout);
+            const int saved = dup(1);
+            const bool redirected = saved >= 0 && dup2(2, 1) >= 0;
+            const int rc = rtx_scene_group_create_from_host(h->host, nullptr, n_gpus, &h->group);
+            fflush(stdout);
+            if (redirected && dup2(saved, 1) < 0) throw "cannot restore standard output\n";
+            if (saved >= 0) close(saved);
+            if (rc != RTX_OK) throw rtx_last_error();
         }
         const double s = rtx_scene_build_seconds(h->group ? rtx_scene_group_scene(h->group, 0) : h->device);
         printf("[ BVH ] %g seconds.\n", static_cast<double>(static_cast<long long>(s * 1000.0)) / 1000.0);   /* scene.hpp:49-51 */

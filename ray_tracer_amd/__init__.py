@@ -110,6 +110,7 @@ EXPORTS = (
     "rtx_scene_bvh_nodes", "rtx_scene_bvh_depth", "rtx_render_device_noalloc", "rtx_render_begin", "rtx_render_end",
     "rtx_scene_group_create", "rtx_scene_group_create_from_host", "rtx_scene_group_destroy", "rtx_scene_group_size",
     "rtx_scene_group_device", "rtx_scene_group_scene", "rtx_render_sharded", "rtx_render_sharded_device", "rtx_scene_group_sync",
+    "rtx_scene_group_set_gather", "rtx_gather_plan",
 )
 
 _lib = None
@@ -182,6 +183,7 @@ def lib() -> C.CDLL:
     L.rtx_render_sharded.argtypes = [vp, C.POINTER(RenderParams), vp]
     L.rtx_render_sharded_device.argtypes = [vp, C.POINTER(RenderParams), C.c_int32, C.POINTER(vp)]
     L.rtx_scene_group_sync.argtypes = [vp, C.c_int32]
+    L.rtx_scene_group_set_gather.argtypes = [vp, C.c_int32]
     L.rtx_untile.argtypes = [C.POINTER(RenderParams), C.c_int32, vp, vp, C.c_int32, vp]
     L.rtx_save_ppm.argtypes = [C.c_char_p, C.c_int32, C.c_int32, vp]
     L.rtx_save_png.argtypes = [C.c_char_p, C.c_int32, C.c_int32, vp]
@@ -451,8 +453,9 @@ class Scene:
         return Frame(rgb, hit, st)
 
     def render_device(self, params: RenderParams, *, rgb_u8=0, hit=0, rgb_i32=0, t=0, stats=0, ticks=0, stream=0) -> None:
-        """Asynchronous frame into device pointers (ints, e.g. torch.Tensor.data_ptr()).  ticks: two uint64 that
-        receive the kernel's first-block start and last-block end on the device's 100 MHz clock."""
+        """Asynchronous frame into device pointers (ints, e.g. torch.Tensor.data_ptr()).  ticks: two uint64 the
+        caller zeroed; afterwards [0] is the complement of the kernel's first-block start and [1] its last-block end on the
+        device's 100 MHz clock (duration = [1] - ~[0])."""
         _check(lib().rtx_render_device_timed(self._h, C.byref(params), rgb_u8 or None, hit or None, rgb_i32 or None,
                                              t or None, stats or None, ticks or None, stream or None))
 
@@ -502,6 +505,10 @@ class SceneGroup:
     def devices(self) -> list:
         return [int(lib().rtx_scene_group_device(self._h, i)) for i in range(self.size)]
 
+    def set_gather(self, mode: int) -> None:
+        """GATHER_ALL (one all-gather) or GATHER_ROOT (sends to the root, which alone ends with the frame's tiles)."""
+        _check(lib().rtx_scene_group_set_gather(self._h, mode))
+
     def render(self, width: int, height: int, **kw) -> np.ndarray:
         """One frame through rtx_render_sharded(): (H, W, 3) uint8."""
         p = make_params(width, height, **kw)
@@ -528,6 +535,26 @@ class SceneGroup:
             self.close()
         except Exception:
             pass
+
+
+GATHER_ALL, GATHER_ROOT = 0, 1
+GATHER_OP_ALLGATHER, GATHER_OP_SEND, GATHER_OP_RECV, GATHER_OP_COPY = 0, 1, 2, 3
+
+
+class GatherOp(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("member", C.c_int32), ("peer", C.c_int32), ("reserved", C.c_int32),
+                ("src_offset", C.c_uint64), ("dst_offset", C.c_uint64), ("bytes", C.c_uint64)]
+
+
+def gather_plan(n_members: int, local_bytes: int, mode: int) -> list:
+    """rtx_gather_plan(): the operations a scene group runs to bring its members' packed tile buffers together."""
+    ops = (GatherOp * (2 * max(1, n_members) + 2))()
+    L = lib()
+    L.rtx_gather_plan.restype = C.c_int32
+    L.rtx_gather_plan.argtypes = [C.c_int32, C.c_uint64, C.c_int32, C.POINTER(GatherOp), C.c_int32]
+    n = L.rtx_gather_plan(n_members, local_bytes, mode, ops, len(ops))
+    _check(min(n, 0))
+    return [ops[i] for i in range(n)]
 
 
 def untile(params: RenderParams, n_ranks: int, gathered_ptr: int, out_ptr: int, bytes_per_pixel: int = 3, stream: int = 0):

@@ -689,6 +689,25 @@ int validate_bvh(HostScene *scene, std::string *err) {
         }
     }
     if (in_leaves != n) { *err = "BVH: the leaves do not cover every triangle"; return RTX_ERR_INVALID; }
+    // Equal-t candidates of different subtrees go to the right one (bvh.hpp:204-208).  The kernels settle such a tie by
+    // the leaves' positions in `indices`, which is the same rule only while the leaf ranges ascend in depth-first order
+    // (left subtree before right), as the reference's builder lays them out (bvh.hpp:151-154).
+    todo.assign(1, 0);
+    uint64_t next_first = 0;
+    while (!todo.empty()) {
+        const rtx_bvh_node &nd = hs.nodes[todo.back()];
+        todo.pop_back();
+        if (nd.count == 0) {
+            todo.push_back(nd.first + 1);
+            todo.push_back(nd.first);
+        } else {
+            if (nd.first != next_first) {
+                *err = "BVH: leaf ranges must follow each other in depth-first order (left subtree first), as BVH::subdivide lays them out";
+                return RTX_ERR_UNSUPPORTED;
+            }
+            next_first += nd.count;
+        }
+    }
     hs.nodes.resize(last + 1);
     for (uint64_t k = 0; k <= last; k++)
         if (!seen[k]) hs.nodes[k] = rtx_bvh_node{{0, 0, 0}, {0, 0, 0}, 0, 0};

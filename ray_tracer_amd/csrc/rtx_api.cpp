@@ -517,10 +517,16 @@ static int scene_create_from_host_impl(const rtx_host_scene *hs, int32_t device,
         d.count = (uint32_t)h.count;
         d.first = h.count == 0 ? (uint32_t)(h.first + 1) : (uint32_t)h.first;
     }
-    // the first record of a sibling pair repeats the second one's {first, count} (see DevNode)
-    for (uint64_t slot = 0; slot + 1 <= m; slot += 2) {
-        nodes[slot].pad[0] = nodes[slot + 1].first;
-        nodes[slot].pad[1] = nodes[slot + 1].count;
+    // The first record of a sibling pair repeats the second one's {first, count} (see DevNode).  A pair is wherever
+    // an inner node points: the reference's builder puts every left child at an odd index (even slot), a caller's
+    // tree may number its nodes differently, so the pairs are taken from the inner nodes and not from the slot parity.
+    nodes[0].pad[0] = nodes[1].first;      // the pair (0, 1) a walk starts with
+    nodes[0].pad[1] = nodes[1].count;
+    for (uint64_t i = 0; i < m; i++) {
+        if (s.nodes[i].count != 0 || s.nodes[i].first == 0 || s.nodes[i].first + 1 >= m) continue;   // leaf, or a blanked gap
+        const uint64_t left = s.nodes[i].first + 1;            // slot of the left child; validate_bvh keeps left + 1 <= m
+        nodes[left].pad[0] = nodes[left + 1].first;
+        nodes[left].pad[1] = nodes[left + 1].count;
     }
     std::vector<rtx::DevTri> tris(n);
     std::vector<rtx::DevMat> mats(n);
@@ -610,7 +616,9 @@ static int create_scene_built_on_device(const rtx_scene_desc *d, rtx_scene **out
         };
         if (e == hipSuccess) e = hipMalloc(&sc->d_tris, n * sizeof(rtx::DevTri));
         if (e == hipSuccess) e = hipMalloc(&sc->d_mats, n * sizeof(rtx::DevMat));
-        while (!vertices_up.load()) std::this_thread::yield();      // the build waits for the vertices, nothing waits for these
+        // the build waits for the vertices, nothing waits for these: sleep through the vertex upload rather than spin on
+        // a core that the upload's own copy threads (and, in a scene group, the other devices' uploads) want
+        while (!vertices_up.load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(200));
         if (d->normals) stage(t_normals, d->normals, 3 * n * sizeof(double));
         stage(t_colors, d->colors, 3 * n * sizeof(int32_t));
         stage(t_spec, d->specularity, n * sizeof(int32_t));
@@ -833,10 +841,12 @@ static int render_device_timed_impl(rtx_scene *sc, const rtx_render_params *p, v
             sc->slot_key[k].clear();
             HIP_TRY(hipMalloc(&sc->d_scratch[k], need));
             sc->scratch_bytes[k] = need;
+            // the work counters start at zero; from then on every launch leaves them at zero again (the last wave
+            // out of render_kernel), so no clearing dispatch sits in front of a frame
+            HIP_TRY(hipMemset(sc->d_scratch[k], 0, rtx::kScratchHeaderBytes));
         }
     }
     bind_scratch(&plan, sc->d_scratch[slot]);
-    HIP_TRY(hipMemsetAsync(r.work, 0, rtx::kScratchHeaderBytes, st));
     // The work-queue table depends only on the launch geometry: the slot keeps it until a launch with
     // another geometry (or a smaller lane count, which moves nothing: the table sits in front) uses it.
     const std::vector<int64_t> key = {r.W, r.H, r.tile_w, r.tile_h, r.tile_rank, r.tile_count, plan.n_queues, plan.macro, plan.centre_first};
@@ -853,10 +863,6 @@ static int render_device_timed_impl(rtx_scene *sc, const rtx_render_params *p, v
         HIP_TRY(hipMalloc(&log.p, n_waves * 32));
         HIP_TRY(hipMemset(log.p, 0, n_waves * 32));
         r.wave_log = (unsigned long long *)log.p;
-    }
-    if (d_ticks) {
-        HIP_TRY(hipMemsetAsync(d_ticks, 0xff, 8, st));
-        HIP_TRY(hipMemsetAsync((char *)d_ticks + 8, 0x00, 8, st));
     }
     HIP_TRY(rtx::launch_render(sc->dev, r, plan.pruned, d_stats != nullptr, plan.block, (uint32_t)plan.grid_blocks, st));
     HIP_TRY(hipEventRecord(sc->slot_done[slot], st));
@@ -881,6 +887,12 @@ static int render_device_noalloc_impl(rtx_scene *sc, const rtx_render_params *p,
     const hipStream_t st = (hipStream_t)stream;
     DeviceGuard guard(sc->device);
     if (!guard.ok) return fail(RTX_ERR_DEVICE, "cannot select the scene's device");
+    // Replaying these launches from a recorded graph is not something this library has verified (an attempt replayed
+    // an empty frame), so a stream that is being captured is refused rather than served with an untested promise.
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &capturing) != hipSuccess) { (void)hipGetLastError(); capturing = hipStreamCaptureStatusNone; }
+    if (capturing != hipStreamCaptureStatusNone && !getenv("RTX_ALLOW_CAPTURE"))
+        return fail(RTX_ERR_UNSUPPORTED, "rtx_render_device_noalloc: the stream is being captured; launch it directly");
     void *base = nullptr;
     HIP_TRY(rtx::noalloc_scratch(sc->device, &base));
     const uint64_t fixed = rtx::kScratchHeaderBytes + rtx::render_order_bytes(r, plan.macro);
@@ -996,6 +1008,9 @@ static int render_end_impl(rtx_scene *sc, int32_t slot, uint8_t *rgb_out, int32_
         if (!h.busy) return fail(RTX_ERR_INVALID, "frame slot holds no frame: call rtx_render_begin() first");
         if (hit_id_out && !h.want_hit) return fail(RTX_ERR_INVALID, "hit ids were not asked for in rtx_render_begin()");
     }
+    // whatever happens below, the slot is free again when this call returns: a frame whose wait failed is lost,
+    // not a reason to refuse every later rtx_render_begin() on the slot
+    struct Release { rtx_scene *sc; rtx_scene::HostSlot &h; ~Release() { std::lock_guard<std::mutex> hold(sc->lock); h.busy = false; } } release{sc, h};
     if (h.pixels) {
         DeviceGuard guard(sc->device);
         if (!guard.ok) return fail(RTX_ERR_DEVICE, "cannot select the scene's device");
@@ -1003,8 +1018,6 @@ static int render_end_impl(rtx_scene *sc, int32_t slot, uint8_t *rgb_out, int32_
         if (rgb_out) rtx::parallel_copy(rgb_out, h.h_rgb, h.pixels * 3);
         if (hit_id_out) rtx::parallel_copy(hit_id_out, h.h_hit, h.pixels * 4);
     }
-    std::lock_guard<std::mutex> hold(sc->lock);
-    h.busy = false;
     return RTX_OK;
 }
 

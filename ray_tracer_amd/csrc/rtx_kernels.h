@@ -36,6 +36,9 @@ inline uint64_t render_waves(const DevRender &rp) {
 // The scratch buffer of a render launch: 1 KiB of work counters, the work-queue table
 // (9 + owned tiles + 2 x macro tiles words, see tile_order_kernel), then the per-lane arrays.
 constexpr uint64_t kScratchHeaderBytes = 1024;
+// Word of that header in which the waves of a launch count themselves out (the queue counters are words 0, 32, ..., 224);
+// the last one zeroes the counters and this word again, so the header must be zero only before a slot's FIRST launch.
+constexpr uint32_t kWavesOutWord = 16;
 inline uint64_t render_order_words(const DevRender &rp, int macro) {
     const uint64_t macros = (uint64_t)((rp.tiles_x + macro - 1) / macro) * (uint64_t)((rp.tiles_y + macro - 1) / macro);
     return 9 + (uint64_t)rp.owned_tiles + 2 * macros;

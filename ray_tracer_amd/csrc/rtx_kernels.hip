@@ -846,10 +846,21 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
         rp.wave_log[4 * gw] = wave_t0;
         rp.wave_log[4 * gw + 1] = wall_clock64();
     }
-    // first wave start / last wave end of the launch, one pair of atomics per block
+    // first wave start / last wave end of the launch, one pair of atomics per block.  Both are maxima over a pair
+    // the caller zeroed (the start as its complement), so that no clearing dispatch has to precede the launch.
     if (rp.ticks && threadIdx.x == 0) {
-        atomicMin(&rp.ticks[0], wave_t0);
+        atomicMax(&rp.ticks[0], ~wave_t0);
         atomicMax(&rp.ticks[1], (unsigned long long)wall_clock64());
+    }
+    // The last wave out puts the work counters back to zero for the next launch that uses this scratch slot
+    // (launches that share a slot are ordered one behind the other), so a frame costs no dispatch but its own.
+    if (lane == 0) {
+        __threadfence();
+        const uint32_t out = atomicAdd(rp.work + kWavesOutWord, 1u) + 1u;
+        if (out == gridDim.x * waves_per_block) {
+            for (uint32_t q = 0; q < 8u; q++) atomicExch(rp.work + q * 32u, 0u);
+            atomicExch(rp.work + kWavesOutWord, 0u);
+        }
     }
 }
 

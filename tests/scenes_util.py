@@ -28,6 +28,18 @@ def soup(seed, n=300, *, extent=4.0, tri_size=1.2, point_lights=True, exotic_spe
     return verts.reshape(n, 9), colors, spec, refl, kw
 
 
+def renumber_with_gap(nodes):
+    """The same tree with one unused record after the root, as builders that start their node counter at 2 number it:
+    every left child then sits at an even index (the reference's builder puts them at odd ones, bvh.hpp:148-149)."""
+    out = np.zeros(len(nodes) + 1, dtype=nodes.dtype)
+    out[0] = nodes[0]
+    out[2:] = nodes[1:]
+    inner = out["count"] == 0
+    inner[1] = False
+    out["first"][inner] += 1
+    return out
+
+
 def untile_reference(gathered, W, H, tile_w, tile_h, n_ranks, bpp=3):
     """numpy restatement of the tile re-assembly: gathered is [rank][local tile][tile_h][tile_w][bpp]."""
     tiles_x = (W + tile_w - 1) // tile_w

@@ -38,8 +38,9 @@ def test_overlapping_frames_equal_frames_rendered_alone():
         torch.cuda.synchronize()
         for k in range(len(jobs)):
             assert np.array_equal(bufs[k].cpu().numpy(), alone[k]), (rep, k)
-    t = ticks.cpu().numpy().reshape(-1, 2)
-    assert (t[:, 1] > t[:, 0]).all()           # every launch left its start and end on the device clock
+    t = ticks.cpu().numpy().astype(np.uint64).reshape(-1, 2)
+    # every launch left its start (as its complement) and its end on the device clock
+    assert (t[:, 0] != 0).all() and (t[:, 1] > ~t[:, 0]).all()
 
 
 def test_sharded_renderer_single_rank_with_frames_in_flight():

@@ -73,6 +73,28 @@ def test_soup_point_lights_rotations_bit_exact(seed, mode):
     dev.close()
 
 
+@pytest.mark.parametrize("mode", [rt.TRAVERSAL_REFERENCE, rt.TRAVERSAL_PRUNED])
+def test_caller_tree_with_left_children_at_even_indices(mode):
+    """The same tree numbered from two (one unused record after the root): sibling pairs then start at odd device
+    slots.  The frame and the census must not notice."""
+    from scenes_util import renumber_with_gap
+
+    v, col, spec, refl, cam = soup(6, n=400)
+    built = rt.HostScene.from_arrays(v, col, spec, refl, **cam).arrays()
+    moved = rt.HostScene.from_arrays(v, col, spec, refl, nodes=renumber_with_gap(built["nodes"]), indices=built["indices"], **cam)
+    dev = rt.Scene(moved)
+    ora = OracleScene.from_arrays(v, col, spec, refl, **cam)
+    want = ora.render(160, 120, depth=3, want_t=True)
+    got = dev.render(160, 120, depth=3, traversal=mode, want_stats=True)
+    assert np.array_equal(got.hit, want["hit"])
+    assert np.array_equal(got.rgb, want["rgb_u8"])
+    if mode == rt.TRAVERSAL_REFERENCE:
+        have = got.stats.as_dict()
+        have.pop("kernel_ms")
+        assert have == want["census"].as_dict()
+    dev.close()
+
+
 def test_soup_census(seed=4):
     _, dev, ora = _pair(seed)
     want = ora.render(96, 96, depth=2)["census"].as_dict()

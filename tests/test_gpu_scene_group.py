@@ -37,6 +37,27 @@ def test_one_member_group_equals_rtx_render(teapot):
     group.close()
 
 
+@pytest.mark.parametrize("gather", [rt.GATHER_ALL, rt.GATHER_ROOT])
+def test_both_exchanges_with_one_member_and_frames_in_flight(teapot, gather):
+    """The all-gather and the send/receive gather to the root (with one member: the root's own copy), ten frames over
+    the four slots whose exchanges share the member's one exchange stream: every frame equals rtx_render's."""
+    scene = rt.Scene(teapot)
+    group = rt.SceneGroup(teapot, devices=[0])
+    group.set_gather(gather)
+    want = scene.render(400, 232, traversal=rt.TRAVERSAL_PRUNED).rgb
+    assert np.array_equal(group.render(400, 232, traversal=rt.TRAVERSAL_PRUNED), want)
+    p = rt.make_params(400, 232, traversal=rt.TRAVERSAL_PRUNED)
+    for k in range(10):
+        group.submit(p, k % 4)
+    group.sync()
+    assert np.array_equal(group.render(400, 232, traversal=rt.TRAVERSAL_PRUNED), want)
+    with pytest.raises(rt.RtxError):
+        group.set_gather(5)
+    with pytest.raises(rt.RtxError):
+        group.render(-4, 16)
+    group.close()
+
+
 def test_frames_in_flight_on_the_four_slots(teapot):
     import torch
     scene = rt.Scene(teapot)

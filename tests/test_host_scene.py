@@ -166,6 +166,29 @@ def test_caller_supplied_bvh_with_the_references_uninitialised_tail():
         rt.HostScene.from_arrays(v, col, spec, refl, nodes=wrap, indices=indices, **cam)
 
 
+def test_caller_supplied_bvh_numbered_from_two_and_leaf_order():
+    """A tree whose left children sit at even indices is accepted as it is; one whose leaf ranges do not ascend in
+    depth-first order is refused, because equal-t ties between leaves are settled by that order (bvh.hpp:204-208)."""
+    from scenes_util import renumber_with_gap, soup
+
+    v, col, spec, refl, cam = soup(7, n=80)
+    built = rt.HostScene.from_arrays(v, col, spec, refl, **cam).arrays()
+    nodes, indices = built["nodes"], built["indices"]
+    moved = renumber_with_gap(nodes)
+    hs = rt.HostScene.from_arrays(v, col, spec, refl, nodes=moved, indices=indices, **cam)
+    got = hs.arrays()["nodes"]
+    assert len(got) == len(nodes) + 1 and got[2:].tobytes() == moved[2:].tobytes()
+    # swap the two children of the root: the same set of leaves, the right subtree's ranges now come first
+    root = nodes[0]
+    assert root["count"] == 0
+    swapped = nodes.copy()
+    l = int(root["first"])
+    swapped[[l, l + 1]] = swapped[[l + 1, l]]
+    with pytest.raises(rt.RtxError) as e:
+        rt.HostScene.from_arrays(v, col, spec, refl, nodes=swapped, indices=indices, **cam)
+    assert "depth-first" in str(e.value)
+
+
 def test_empty_scene_is_an_error():
     with pytest.raises(rt.RtxError):
         rt.HostScene.from_arrays(np.zeros((0, 9)), np.zeros((0, 3)), np.zeros(0), np.zeros(0), camera_position=(0, 0, 0))
