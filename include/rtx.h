@@ -287,10 +287,21 @@ int rtx_render_device(rtx_scene *scene, const rtx_render_params *p, void *d_rgb_
 int rtx_render_device_timed(rtx_scene *scene, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id,
                             void *d_rgb_i32, void *d_t, void *d_stats, void *d_ticks, void *stream);
 
+/* Several frames in ONE launch: n_frames (1..8) frames of the scene with the same parameters, frame f into
+ * d_rgb_u8 + f * rtx_output_pixels(p) * 3 (d_rgb_i32, nullable: + f * rtx_output_pixels(p) * 12).  `cameras`
+ * (nullable) gives every frame its own camera, n_frames x {position[3], rotation in degrees[3]} in host memory,
+ * read before the call returns; NULL renders the scene's camera n_frames times.  The reference renders frame after
+ * frame (src/main.cpp:42-61); here a frame's last pixels, which leave most of the chip idle when a frame is
+ * launched alone, overlap the next frame's first ones inside the one launch -- what frames in flight on several
+ * streams achieve only while every stream has a hardware queue to itself.  d_stats / d_ticks as in
+ * rtx_render_device_timed(), over the whole launch.  Hit ids and t are not written. */
+int rtx_render_device_batch(rtx_scene *scene, const rtx_render_params *p, int32_t n_frames, const double *cameras,
+                            void *d_rgb_u8, void *d_rgb_i32, void *d_stats, void *d_ticks, void *stream);
+
 /* rtx_render_device() for callers that cannot allocate: tight serving loops, harnesses that forbid
  * hipMalloc.  No counterpart in the reference.  Same arguments, same
  * frame, bit for bit; but the launch's scratch (work counters, work-queue table, per-lane shading
- * state) lives in a 32 MiB array that is part of the library's device code, one copy per GPU for
+ * state) lives in a 48 MiB array that is part of the library's device code, one copy per GPU for
  * the life of the process, and the call makes no hipMalloc / hipFree / event or stream creation
  * and no synchronisation: two kernel launches on `stream`, nothing else.  A stream that is
  * being captured into a HIP graph is refused (RTX_ERR_UNSUPPORTED): replay of the two launches is

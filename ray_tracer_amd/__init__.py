@@ -110,7 +110,7 @@ EXPORTS = (
     "rtx_scene_bvh_nodes", "rtx_scene_bvh_depth", "rtx_render_device_noalloc", "rtx_render_begin", "rtx_render_end",
     "rtx_scene_group_create", "rtx_scene_group_create_from_host", "rtx_scene_group_destroy", "rtx_scene_group_size",
     "rtx_scene_group_device", "rtx_scene_group_scene", "rtx_render_sharded", "rtx_render_sharded_device", "rtx_scene_group_sync",
-    "rtx_scene_group_set_gather", "rtx_gather_plan",
+    "rtx_scene_group_set_gather", "rtx_gather_plan", "rtx_render_device_batch",
 )
 
 _lib = None
@@ -195,6 +195,16 @@ def lib() -> C.CDLL:
     L.rtx_host_scene_rebuild_bvh.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
     _lib = L
     return L
+
+
+def version() -> str:
+    """rtx_version(): library name, target and a hash of the render kernels' sources."""
+    return lib().rtx_version().decode()
+
+
+def kernel_build() -> str:
+    """The hash of the render kernels' sources this library was built from (last word of rtx_version())."""
+    return version().split()[-1]
 
 
 def _check(rc: int) -> None:
@@ -458,6 +468,18 @@ class Scene:
         device's 100 MHz clock (duration = [1] - ~[0])."""
         _check(lib().rtx_render_device_timed(self._h, C.byref(params), rgb_u8 or None, hit or None, rgb_i32 or None,
                                              t or None, stats or None, ticks or None, stream or None))
+
+    def render_device_batch(self, params: RenderParams, n_frames: int, *, cameras=None, rgb_u8=0, rgb_i32=0, stats=0, ticks=0, stream=0) -> None:
+        """rtx_render_device_batch(): n_frames frames in one launch, consecutive in the output buffers; cameras: optional
+        (n_frames, 6) array of position + rotation in degrees, one camera per frame."""
+        cam = None
+        if cameras is not None:
+            cam = np.ascontiguousarray(cameras, dtype=np.float64).reshape(n_frames, 6)
+        L = lib()
+        L.rtx_render_device_batch.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(L.rtx_render_device_batch(self._h, C.byref(params), n_frames, cam.ctypes.data if cam is not None else None,
+                                         rgb_u8 or None, rgb_i32 or None, stats or None, ticks or None, stream or None))
 
     def render_begin(self, params: RenderParams, slot: int, want_hit: bool = False) -> None:
         """rtx_render_begin(): queues a frame on `slot` (0..3) on its way to host memory."""

@@ -113,6 +113,13 @@ struct DevRender {
     int32_t tail_lanes;                 // at most this many live lanes: run every kind of step each round
     int32_t also_lanes;                 // a kind with at least this many waiting lanes runs in every round
     int32_t also_leaf, also_shade;      // (inner node steps: also_lanes; triangle steps: also_leaf; shading: also_shade)
+    // several frames in one launch (rtx_render_device_batch): queue q hands out its blocks frame after frame; frame f
+    // writes its pixels f * frame_pixels further on, through camera cams[f] = {position[3], cos x, sin x, cos y, sin y,
+    // cos z, sin z} when has_cams is set (else every frame has the scene's camera)
+    int32_t n_frames, has_cams;
+    uint32_t frame_pixels, frames_pad;
+    double cams[8][9];
+    int32_t lighting_jobs;              // 1: lanes without work take over the lighting of other lanes' surface hits at the end of a launch
     unsigned long long *wave_log;       // diagnostics, or NULL: per wave {start, end, latest block drawn} in 100 MHz ticks and that block (x0 | y0 << 16 | queue << 32)
     unsigned long long *ticks;          // {earliest block start, latest block end} in 100 MHz ticks, or NULL
 };

@@ -290,7 +290,11 @@ extern "C" {
 const char *rtx_last_error(void) { return g_error.c_str(); }
 // for the library's other translation units (rtx_group.cpp): the calling thread's error text
 void rtx_set_last_error_(const char *message) { g_error = message ? message : ""; }
-const char *rtx_version(void) { return "rtx-mi355x 0.1 (gfx950)"; }
+#ifndef RTX_KERNEL_HASH
+#define RTX_KERNEL_HASH "unknown"
+#endif
+// the last word is a hash of the render kernels' sources (see the Makefile)
+const char *rtx_version(void) { return "rtx-mi355x 0.3 (gfx950) kernels " RTX_KERNEL_HASH; }
 
 // ------------------------------------------------------------------ host scenes
 static int host_scene_load_obj_ex_impl(const char *obj_path, const char *preset, uint32_t flags, int32_t device, rtx_host_scene **out) {
@@ -782,6 +786,10 @@ static int plan_render(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8
     r.also_lanes = knob("RTX_ALSO_LANES", 24);
     r.also_leaf = knob("RTX_ALSO_LEAF", 16);
     r.also_shade = knob("RTX_ALSO_SHADE", r.also_lanes);
+    r.lighting_jobs = knob("RTX_LIGHTING_JOBS", 1);
+    r.n_frames = 1;
+    r.has_cams = 0;
+    r.frame_pixels = 0;
     if (r.w_inner < 1 || r.w_leaf < 1 || r.w_shade < 1) return fail(RTX_ERR_INVALID, "scheduler weights must be positive");
     plan->grid_blocks = 0;
     if (r.W == 0 || r.H == 0 || r.owned_tiles == 0) return RTX_OK;
@@ -811,14 +819,45 @@ static void bind_scratch(LaunchPlan *plan, void *base) {
     r.tile_order = (const uint32_t *)((char *)base + rtx::kScratchHeaderBytes);
     r.scratch_lanes = lanes;
     r.scratch_f64 = (double *)((char *)base + rtx::kScratchHeaderBytes + rtx::render_order_bytes(r, plan->macro));
-    r.scratch_i32 = (int32_t *)((char *)r.scratch_f64 + lanes * (4 + (uint64_t)r.depth) * 8);
+    r.scratch_i32 = (int32_t *)((char *)r.scratch_f64 + lanes * rtx::render_lane_f64s(r.depth) * 8);
+}
+
+// Turns a launch plan into one over `n_frames` frames (see DevRender::n_frames): the queues hand out every block once
+// per frame, frame f writes f * (pixels of one frame) further on, with its own camera if `cameras` (n_frames x
+// {position[3], rotation in degrees[3]}) is given.
+static int plan_frames(rtx_scene *sc, const rtx_render_params *p, int32_t n_frames, const double *cameras, LaunchPlan *plan) {
+    rtx::DevRender &r = plan->r;
+    if (n_frames < 1 || n_frames > 8) return fail(RTX_ERR_INVALID, "a launch renders 1..8 frames");
+    if (r.hit || r.t) return fail(RTX_ERR_INVALID, "hit ids / t are written by single-frame launches only");
+    const uint64_t frame_pixels = rtx_output_pixels(p);
+    if (frame_pixels * (uint64_t)n_frames >= (1ull << 32) || (uint64_t)r.total_blocks * (uint64_t)n_frames >= (1ull << 26))
+        return fail(RTX_ERR_UNSUPPORTED, "more than 2^32 pixels in one launch");
+    r.n_frames = n_frames;
+    r.frame_pixels = (uint32_t)frame_pixels;
+    r.has_cams = cameras ? 1 : 0;
+    for (int32_t f = 0; cameras && f < n_frames; f++) {
+        const double *c = cameras + 6 * f;
+        double *o = r.cams[f];
+        for (int k = 0; k < 3; k++) o[k] = c[k];
+        // one sincos() per axis, as in finish_device_scene (Vector3::rotateX/Y/Z, vector3.hpp:54-82)
+        sincos((c[3] / 180.0) * M_PI, &o[4], &o[3]);
+        sincos((c[4] / 180.0) * M_PI, &o[6], &o[5]);
+        sincos((c[5] / 180.0) * M_PI, &o[8], &o[7]);
+    }
+    // more work per launch may keep more of the chip busy: the grid was sized for one frame's blocks
+    const uint64_t wpb = plan->block / 64;
+    const uint64_t resident = (uint64_t)sc->cu_count * (uint64_t)rtx::render_blocks_per_cu() * (256 / plan->block);
+    plan->grid_blocks = std::min<uint64_t>(((uint64_t)r.total_blocks * (uint64_t)n_frames + wpb - 1) / wpb, std::max<uint64_t>(resident, plan->grid_blocks));
+    return RTX_OK;
 }
 
 static int render_device_timed_impl(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id, void *d_rgb_i32, void *d_t,
-                            void *d_stats, void *d_ticks, void *stream) {
+                            void *d_stats, void *d_ticks, void *stream, int32_t n_frames = 1, const double *cameras = nullptr) {
     LaunchPlan plan;
     if (int rc = plan_render(sc, p, d_rgb_u8, d_hit_id, d_rgb_i32, d_t, d_stats, d_ticks, &plan)) return rc;
     if (plan.grid_blocks == 0) return RTX_OK;
+    if (n_frames != 1 || cameras)
+        if (int rc = plan_frames(sc, p, n_frames, cameras, &plan)) return rc;
     rtx::DevRender &r = plan.r;
     const hipStream_t st = (hipStream_t)stream;
     DeviceGuard guard(sc->device);
@@ -899,7 +938,7 @@ static int render_device_noalloc_impl(rtx_scene *sc, const rtx_render_params *p,
     const uint64_t per_block = plan.block * rtx::render_lane_bytes(r.depth);
     if (fixed + per_block > rtx::kNoallocScratchBytes)
         return fail(RTX_ERR_UNSUPPORTED, "rtx_render_device_noalloc: the frame has more tiles than the fixed scratch array's "
-                                         "work-queue table holds (32 MiB in all; use larger tiles or rtx_render_device)");
+                                         "work-queue table holds (48 MiB in all; use larger tiles or rtx_render_device)");
     plan.grid_blocks = std::min<uint64_t>(plan.grid_blocks, (rtx::kNoallocScratchBytes - fixed) / per_block);
     bind_scratch(&plan, base);
     // two kernels and nothing else on the stream: the first one clears the last call's counters and writes the table
@@ -1241,6 +1280,11 @@ int rtx_scene_create_with_builder(const rtx_scene_desc *desc, int32_t builder, r
 int rtx_render_device_timed(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id, void *d_rgb_i32, void *d_t,
                             void *d_stats, void *d_ticks, void *stream) {
     return guarded([&]() -> int { return render_device_timed_impl(sc, p, d_rgb_u8, d_hit_id, d_rgb_i32, d_t, d_stats, d_ticks, stream); });
+}
+
+int rtx_render_device_batch(rtx_scene *sc, const rtx_render_params *p, int32_t n_frames, const double *cameras, void *d_rgb_u8,
+                            void *d_rgb_i32, void *d_stats, void *d_ticks, void *stream) {
+    return guarded([&]() -> int { return render_device_timed_impl(sc, p, d_rgb_u8, nullptr, d_rgb_i32, nullptr, d_stats, d_ticks, stream, n_frames, cameras); });
 }
 
 int rtx_render_device_noalloc(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id, void *d_rgb_i32, void *d_t,

@@ -8,9 +8,8 @@
 // device writes the row-major frame.  One host thread drives all devices (every call below is
 // asynchronous), with a single-process communicator per device from ncclCommInitAll.  A device has
 // ONE exchange stream for its communicator -- RCCL wants a communicator's operations issued in one
-// order on one stream -- of the highest priority the device offers (its kernels must find room on
-// a chip that persistent render launches keep full); frames in flight render on their own streams
-// and meet the exchange stream through events.  RCCL is bound at first use with dlopen, so the
+// order on one stream; frames in flight render on their own streams and meet the exchange stream
+// through events.  RCCL is bound at first use with dlopen, so the
 // library itself loads on machines without it and shares the copy a host program (PyTorch) may
 // already have loaded.
 #include <dlfcn.h>
@@ -182,7 +181,12 @@ int group_create(const int32_t *devices, int32_t n_devices, rtx_scene_group **ou
         GRP_HIP(hipSetDevice(g->devices[i]));
         int least = 0, greatest = 0;                 // numerically: greatest priority = the smaller number
         GRP_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        GRP_HIP(hipStreamCreateWithPriority(&d.exchange, hipStreamNonBlocking, greatest));
+        // Default priority.  A high-priority exchange stream would let the exchange's kernels pass the persistent render
+        // launches that keep the chip full, but on this runtime it hangs as soon as the process has more live streams than
+        // hardware queues (four frames in flight + this stream with the default four queues): RTX_GROUP_EXCHANGE_HIGH=1
+        // asks for it all the same, for a process that sets GPU_MAX_HW_QUEUES above its stream count.
+        const char *high = getenv("RTX_GROUP_EXCHANGE_HIGH");
+        GRP_HIP(hipStreamCreateWithPriority(&d.exchange, hipStreamNonBlocking, high && *high == '1' ? greatest : least));
         for (int f = 0; f < rtx_scene_group::kFrames; f++) {
             GRP_HIP(hipStreamCreateWithFlags(&d.stream[f], hipStreamNonBlocking));
             GRP_HIP(hipEventCreateWithFlags(&d.rendered[f], hipEventDisableTiming));

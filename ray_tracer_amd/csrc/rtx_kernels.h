@@ -12,9 +12,10 @@ namespace rtx {
 // must equal RTX_LAYOUT_PACKED_TILES in include/rtx.h (checked in rtx_api.cpp)
 constexpr int RTX_LAYOUT_PACKED_TILES_ = 1;
 
-// LDS bytes of a render block's traversal stacks: one u32 slot per tree level per lane.
+// LDS bytes of a render block's traversal stacks: one u32 slot per tree level per lane, and one more row in
+// which a lane counts the parties still at work on its pixel (see the lighting jobs in render_kernel).
 inline size_t render_lds_bytes(int32_t bvh_depth, uint32_t block_threads) {
-    return (size_t)(bvh_depth + 1) * block_threads * sizeof(uint32_t);
+    return (size_t)(bvh_depth + 2) * block_threads * sizeof(uint32_t);
 }
 // Sibling pairs of the top of the tree a render block keeps in LDS behind its stacks: what is left of
 // the block's share of a CU's 160 KiB (render_blocks_per_cu() blocks of 256 threads, or their
@@ -44,10 +45,13 @@ inline uint64_t render_order_words(const DevRender &rp, int macro) {
     return 9 + (uint64_t)rp.owned_tiles + 2 * macros;
 }
 inline uint64_t render_order_bytes(const DevRender &rp, int macro) { return (render_order_words(rp, macro) * 4 + 255) / 256 * 256; }
-inline uint64_t render_lane_bytes(int32_t depth) { return (4 + (uint64_t)depth) * 8 + (1 + 3 * (uint64_t)depth) * 4; }
+// per-lane scratch (struct Scratch in rtx_kernels.hip): doubles, then 32-bit words, each field-major over the resident lanes
+inline uint64_t render_lane_f64s(int32_t depth) { return 5 + 2 * (uint64_t)depth; }
+inline uint64_t render_lane_i32s(int32_t depth) { return 10 + 3 * (uint64_t)depth; }
+inline uint64_t render_lane_bytes(int32_t depth) { return render_lane_f64s(depth) * 8 + render_lane_i32s(depth) * 4; }
 
 // Size of the file-scope device array behind rtx_render_device_noalloc, per GPU.
-constexpr uint64_t kNoallocScratchBytes = 32ull << 20;
+constexpr uint64_t kNoallocScratchBytes = 48ull << 20;
 // Device address of that array on `device`, which must be current (looked up once per device).
 hipError_t noalloc_scratch(int device, void **ptr);
 

@@ -52,6 +52,12 @@ __device__ __forceinline__ double smax(double a, double b) { return (a < b) ? b 
 
 __device__ __forceinline__ V3 ld3(const double *p) { return {p[0], p[1], p[2]}; }
 
+// the value lane `l` (wave-uniform) holds
+__device__ __forceinline__ double lane_value(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
 // A node pair or a triangle is fetched with 16-byte loads issued back to back and kept
 // in registers; pin() stops the compiler from sinking some of those loads below the
 // first arithmetic (it would, to save registers, and a step would then pay two or three
@@ -365,13 +371,31 @@ __device__ __forceinline__ double query_tmax(uint32_t p, uint32_t n_point) {
     return (path_kind(p) == 1u && path_li(p) < n_point) ? 1.0 : RTX_INF;
 }
 
-// per-lane slice of the scratch buffer: field-major arrays of `n` lanes each
+// A lighting job (see render_kernel): the lane computes the lighting of another lane's surface hit.  Only with one
+// sample per pixel, so the sample bits of `path` are free: bit 4 marks the job, bits 5..10 name the lane that owns
+// the pixel.
+constexpr uint32_t kJob = 1u << 4;
+__device__ __forceinline__ uint32_t job_owner(uint32_t p) { return (p >> 5) & 63u; }
+
+// per-lane slice of the scratch buffer: field-major arrays of `n` lanes each.  `depth` is the launch's recursion
+// depth: a pixel has at most depth + 1 surface hits ("levels").  A level's record is its localColor (color x lighting,
+// truncated: scene.hpp:113) and reflectivity; a level whose lighting was handed to a lighting job holds the triangle's
+// colour instead, its bit is set in `waiting`, and the job delivers the total lighting.
 struct Scratch {
-    double *f64;         // [0..2] -ray  [3] lighting sum  [4 + level] reflectivity
-    int32_t *i32;        // [0] triangle position  [1 + 3*level + c] localColor channel c
+    double *f64;         // [0..2] -ray  [3] lighting sum  [4 + level] reflectivity  [4 + depth + level] total lighting (handed-over levels)
+    int32_t *i32;        // [0] triangle position  [1 + 3*level + c] colour channel c  [4 + 3*depth ..] see below
     uint64_t n, id;
+    uint32_t depth;
     __device__ __forceinline__ double &f(uint32_t field) const { return f64[(uint64_t)field * n + id]; }
     __device__ __forceinline__ int32_t &i(uint32_t field) const { return i32[(uint64_t)field * n + id]; }
+    __device__ __forceinline__ double &refl(uint32_t level) const { return f(4u + level); }
+    __device__ __forceinline__ double &total(uint32_t level) const { return f(4u + depth + level); }
+    __device__ __forceinline__ int32_t &colour(uint32_t level, uint32_t c) const { return i(1u + 3u * level + c); }
+    // what is left of a pixel whose chain of closest-hit queries has ended while lighting jobs are still out
+    __device__ __forceinline__ int32_t &chain_end() const { return i(4u + 3u * depth); }     // levels below the innermost colour | (innermost = a waiting level) << 8
+    __device__ __forceinline__ int32_t &out_index() const { return i(5u + 3u * depth); }
+    __device__ __forceinline__ int32_t &waiting() const { return i(6u + 3u * depth); }       // bit per level: total lighting comes from a job
+    __device__ __forceinline__ int32_t &innermost(uint32_t c) const { return i(7u + 3u * depth + c); }
 };
 
 // What the traversal steps and the scheduler read in every round, fetched from the argument
@@ -532,7 +556,7 @@ __device__ __forceinline__ void leaf_step(Lane &L, const Hot &hot, const uint32_
 }
 
 // src/main.cpp:78-83: camera ray of pixel (col,row), sample s
-__device__ __forceinline__ void primary_ray(Lane &L, const DevScene &sc, const DevRender &rp, int col, int row, uint32_t s) {
+__device__ __forceinline__ void primary_ray(Lane &L, const DevScene &sc, const DevRender &rp, int col, int row, uint32_t s, uint32_t frame) {
     // putPixel inverted (src/main.cpp:90-94): row = -y + H/2 - 1, col = x + W/2
     const int x = col - rp.W / 2, y = rp.H / 2 - 1 - row;
     double fx = (double)x, fy = (double)y;
@@ -544,11 +568,16 @@ __device__ __forceinline__ void primary_ray(Lane &L, const DevScene &sc, const D
         fy = fy + (double)(z & 0xFFFFFFFFull) * (1.0 / 4294967296.0);
     }
     // Scene::toViewport (scene.hpp:81-87), then rotateX, rotateY, rotateZ (vector3.hpp:54-82)
+    // the scene's camera, or the frame's own in a launch over several frames
+    const bool own = rp.has_cams != 0;
+    const double *cam = rp.cams[own ? frame : 0u];
+    const double cx = own ? cam[3] : sc.cx, sx = own ? cam[4] : sc.sx, cy = own ? cam[5] : sc.cy, sy = own ? cam[6] : sc.sy,
+                 cz = own ? cam[7] : sc.cz, sz = own ? cam[8] : sc.sz;
     V3 vp = {fx * rp.px, fy * rp.py, sc.viewport[2]};
-    V3 rx = {vp.x, sc.cx * vp.y - sc.sx * vp.z, sc.sx * vp.y + sc.cx * vp.z};
-    V3 ry = {sc.cy * rx.x + sc.sy * rx.z, rx.y, (-sc.sy) * rx.x + sc.cy * rx.z};
-    L.r = {sc.cz * ry.x - sc.sz * ry.y, sc.sz * ry.x + sc.cz * ry.y, ry.z};
-    L.o = {sc.cam[0], sc.cam[1], sc.cam[2]};
+    V3 rx = {vp.x, cx * vp.y - sx * vp.z, sx * vp.y + cx * vp.z};
+    V3 ry = {cy * rx.x + sy * rx.z, rx.y, (-sy) * rx.x + cy * rx.z};
+    L.r = {cz * ry.x - sz * ry.y, sz * ry.x + cz * ry.y, ry.z};
+    L.o = {own ? cam[0] : sc.cam[0], own ? cam[1] : sc.cam[1], own ? cam[2] : sc.cam[2]};
     L.path = make_path(0, 0, s, 0);
 }
 
@@ -557,20 +586,36 @@ struct PixelSum {
     int r, g, b;
 };
 
-// A finished query (scene.hpp:89-183).  Leaves the lane with a new query (ST_INNER) or done.
-template <bool PRUNE, bool STATS>
+// A finished query (scene.hpp:89-183).  Leaves the lane with a new query (ST_INNER) or without a pixel (ST_FETCH).
+//
+// A pixel is a chain of closest-hit queries (camera ray, then up to `depth` reflections); every surface hit
+// ("level") also needs its lighting: one shadow query per light, in the order of computeTotalLighting.  Levels that
+// wait for their reflected colour keep their localColor and reflectivity in the lane's scratch, and when the chain
+// has ended the levels are blended innermost first (scene.hpp:120-122) with Color's truncating arithmetic.
+//
+// TAIL = false is the launch's steady state: a lane does all of that for its pixel, one query after the other.
+// TAIL = true is the code of a wave whose queues are empty and that has lanes with nothing left to do (see
+// render_kernel).  There a surface hit's lighting may have been handed to such a lane as a lighting job
+// (`handed_over`, decided by the caller just before this step) while the owner follows the reflection at once -- the
+// shadow queries of a hit and its reflection query do not depend on each other, only the blend needs both -- and the
+// pixel is finished by whoever finishes last: pend[lane] (LDS) counts the parties still at work on that lane's
+// pixel, the owner's chain and its lighting jobs.  A job runs this same code: it starts from a copy of the owner's
+// closest-hit result, walks the lights and delivers the total into the OWNER's scratch.
+template <bool PRUNE, bool STATS, bool TAIL>
 __device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScene &sc, const DevRender &rp, const Scratch &scr,
-                                           Counters &c, uint32_t root_ref) {
+                                           Counters &c, uint32_t root_ref, bool handed_over, uint32_t *pend, uint32_t lane) {
     const uint32_t n_lights = sc.n_point + sc.n_dir;
     const uint32_t kind = path_kind(L.path), s = path_s(L.path);
+    const bool job = TAIL && (L.path & kJob) != 0;
     uint32_t d = path_d(L.path), li = path_li(L.path);
-    bool path_done = false;
+    bool path_done = false;    // the chain has ended: (cr, cg, cb) is its innermost colour
     int cr = sc.bg[0], cg = sc.bg[1], cb = sc.bg[2];
-    bool lights = false;
+    bool lights = false;       // a shadow query was answered, or the first one is due
+    bool elsewhere = false;    // TAIL: the lighting of this hit is a job's business
     if (kind == 0) {
         // Scene::traceRay after the closest-hit query (scene.hpp:97-111)
-        if (STATS) c.v[d == 0 ? C_PRIMARY : C_REFLECTION]++;
-        if (d == 0 && s == 0 && (rp.hit || rp.t)) {
+        if (STATS && !job) c.v[d == 0 ? C_PRIMARY : C_REFLECTION]++;
+        if (d == 0 && s == 0 && (rp.hit || rp.t)) {                     // (a job carries its marks in the sample bits: s != 0)
             const uint64_t k = (uint64_t)(L.pix >> 16) * (uint64_t)rp.W + (uint64_t)(L.pix & 0xFFFFu);
             if (rp.hit) rp.hit[k] = (L.best_pos >= 0) ? (int32_t)sc.tris[L.best_pos].orig_id : -1;
             if (rp.t) rp.t[k] = L.best_t;
@@ -578,14 +623,15 @@ __device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScen
         if (L.best_pos < 0) {
             path_done = true;                                           // backgroundColor, scene.hpp:101-103
         } else {
-            if (STATS) c.v[C_CLOSEST]++;
+            if (STATS && !job) c.v[C_CLOSEST]++;
             L.o = add(L.o, smul(L.best_t, L.r));                        // point, scene.hpp:105
             const V3 v = muls(L.r, -1.0);                               // -ray, vector3.hpp:108-110
             scr.f(0) = v.x; scr.f(1) = v.y; scr.f(2) = v.z;
             scr.f(3) = sc.ambient;                                      // scene.hpp:128
             scr.i(0) = L.best_pos;
             li = 0;
-            lights = true;
+            elsewhere = TAIL && handed_over;
+            lights = !elsewhere;
         }
     } else {
         // the rest of Scene::computeLighting (scene.hpp:159-182) with light = r, point = o
@@ -615,73 +661,292 @@ __device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScen
         lights = true;
     }
     __builtin_amdgcn_sched_barrier(0);
+    Scratch px = scr;          // TAIL: the scratch of the pixel this step finishes, the lane's own or a job's owner's
+    bool finish = false;       // TAIL: this lane is the last party of that pixel
     if (lights) {
         if (li < n_lights) {
             // computeTotalLighting (scene.hpp:130-142): point lights first (light = position -
             // point, tMax = 1), then directional ones (light = direction, tMax = inf)
             const V3 lv = ld3(sc.lights[li].v);
             L.r = (li < sc.n_point) ? sub(lv, L.o) : lv;
-            L.path = make_path(1, d, s, li);
+            L.path = (L.path & 0xFFFEu) | 1u | (li << 16);              // a shadow query of light li; depth and sample (or job marks) stay
             start_query(L, sc, PRUNE, root_ref);
             return;
         }
-        // Color * double truncates each channel (color.hpp:47-53)
+        if (job) {
+            // the job is done: the level's total lighting goes to the pixel's owner, and if this was the last party at
+            // work on the pixel, this lane finishes it
+            const uint32_t owner = job_owner(L.path);
+            px.id = scr.id - lane + owner;
+            px.total(d) = scr.f(3);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            const uint32_t left = __hip_atomic_fetch_sub(pend + owner, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - 1u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            L.state = ST_FETCH;
+            if (left != 0u) return;
+            finish = true;
+        } else {
+            // Color * double truncates each channel (color.hpp:47-53)
+            const int32_t pos = scr.i(0);
+            const DevMat &mt = sc.mats[pos];
+            const double total = scr.f(3);
+            const int lr = to_int(mt.color[0] * total), lg = to_int(mt.color[1] * total), lb = to_int(mt.color[2] * total);
+            const double refl = mt.reflectivity;
+            if (d == (uint32_t)rp.depth || refl < 0) {                  // scene.hpp:115-117
+                cr = lr; cg = lg; cb = lb;
+                path_done = true;
+            } else {
+                scr.colour(d, 0) = lr; scr.colour(d, 1) = lg; scr.colour(d, 2) = lb;
+                scr.refl(d) = refl;
+                const V3 v = {scr.f(0), scr.f(1), scr.f(2)};
+                L.r = reflect_ray(v, ld3(sc.tris[pos].n));              // scene.hpp:119
+                L.path = make_path(0, d + 1, s, 0);
+                start_query(L, sc, PRUNE, root_ref);
+                return;
+            }
+        }
+    }
+    uint32_t levels = d;       // levels below the innermost colour
+    bool inner_waits = false;  // TAIL: the innermost colour is a level whose lighting is a job's
+    if (TAIL && elsewhere) {
+        // the level's record holds the triangle's colour until the blend, where the job's total meets it
         const int32_t pos = scr.i(0);
         const DevMat &mt = sc.mats[pos];
-        const double total = scr.f(3);
-        const int lr = to_int(mt.color[0] * total), lg = to_int(mt.color[1] * total), lb = to_int(mt.color[2] * total);
+        scr.colour(d, 0) = mt.color[0]; scr.colour(d, 1) = mt.color[1]; scr.colour(d, 2) = mt.color[2];
+        scr.waiting() |= (int32_t)(1u << d);
         const double refl = mt.reflectivity;
         if (d == (uint32_t)rp.depth || refl < 0) {                      // scene.hpp:115-117
-            cr = lr; cg = lg; cb = lb;
             path_done = true;
+            inner_waits = true;
         } else {
-            scr.i(1 + 3 * d) = lr; scr.i(2 + 3 * d) = lg; scr.i(3 + 3 * d) = lb;
-            scr.f(4 + d) = refl;
-            const V3 v = {scr.f(0), scr.f(1), scr.f(2)};
-            L.r = reflect_ray(v, ld3(sc.tris[pos].n));                  // scene.hpp:119
+            scr.refl(d) = refl;
+            L.r = reflect_ray(muls(L.r, -1.0), ld3(sc.tris[pos].n));    // scene.hpp:119; L.r is still the ray that hit
             L.path = make_path(0, d + 1, s, 0);
             start_query(L, sc, PRUNE, root_ref);
             return;
         }
     }
-    if (!path_done) return;
-    // localColor * (1 - reflectivity) + reflectedColor * reflectivity (scene.hpp:122), innermost first
-    while (d > 0) {
-        d--;
-        const int lr = scr.i(1 + 3 * d), lg = scr.i(2 + 3 * d), lb = scr.i(3 + 3 * d);
-        const double refl = scr.f(4 + d);
-        const double keep = 1 - refl;
-        // int + int wraps on both machines
-        cr = (int)((uint32_t)to_int(lr * keep) + (uint32_t)to_int(cr * refl));
-        cg = (int)((uint32_t)to_int(lg * keep) + (uint32_t)to_int(cg * refl));
-        cb = (int)((uint32_t)to_int(lb * keep) + (uint32_t)to_int(cb * refl));
+    if (!path_done && !finish) return;
+    uint32_t out = L.out;
+    if (TAIL) {
+        if (path_done) {
+            // the chain has ended; lighting jobs may still be out: leave what the blend needs and count this party out
+            scr.chain_end() = (int32_t)(levels | (inner_waits ? 0x100u : 0u));
+            scr.out_index() = (int32_t)out;
+            scr.innermost(0) = cr; scr.innermost(1) = cg; scr.innermost(2) = cb;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            const uint32_t left = __hip_atomic_fetch_sub(pend + lane, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - 1u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            L.state = ST_FETCH;
+            if (left != 0u) return;
+        }
+        // the last party blends from the pixel's records
+        const uint32_t e = (uint32_t)px.chain_end(), waiting = (uint32_t)px.waiting();
+        levels = e & 0xFFu;
+        out = (uint32_t)px.out_index();
+        if (e >> 8) {
+            const double total = px.total(levels);
+            cr = to_int(px.colour(levels, 0) * total); cg = to_int(px.colour(levels, 1) * total); cb = to_int(px.colour(levels, 2) * total);
+        } else {
+            cr = px.innermost(0); cg = px.innermost(1); cb = px.innermost(2);
+        }
+        // localColor * (1 - reflectivity) + reflectedColor * reflectivity (scene.hpp:122), innermost first
+        while (levels > 0) {
+            levels--;
+            int lr = px.colour(levels, 0), lg = px.colour(levels, 1), lb = px.colour(levels, 2);
+            if ((waiting >> levels) & 1u) {
+                const double total = px.total(levels);
+                lr = to_int(lr * total); lg = to_int(lg * total); lb = to_int(lb * total);
+            }
+            const double refl = px.refl(levels);
+            const double keep = 1 - refl;
+            cr = (int)((uint32_t)to_int(lr * keep) + (uint32_t)to_int(cr * refl));
+            cg = (int)((uint32_t)to_int(lg * keep) + (uint32_t)to_int(cg * refl));
+            cb = (int)((uint32_t)to_int(lb * keep) + (uint32_t)to_int(cb * refl));
+        }
+    } else {
+        // localColor * (1 - reflectivity) + reflectedColor * reflectivity (scene.hpp:122), innermost first
+        while (levels > 0) {
+            levels--;
+            const int lr = scr.colour(levels, 0), lg = scr.colour(levels, 1), lb = scr.colour(levels, 2);
+            const double refl = scr.refl(levels);
+            const double keep = 1 - refl;
+            // int + int wraps on both machines
+            cr = (int)((uint32_t)to_int(lr * keep) + (uint32_t)to_int(cr * refl));
+            cg = (int)((uint32_t)to_int(lg * keep) + (uint32_t)to_int(cg * refl));
+            cb = (int)((uint32_t)to_int(lb * keep) + (uint32_t)to_int(cb * refl));
+        }
     }
     // putPixel (src/main.cpp:90-94) + the clamp of saveCanvas (src/main.cpp:107)
-    const uint64_t out = L.out;
-    if (rp.spp == 1) {
+    if (TAIL || rp.spp == 1) {
         if (rp.rgb) {
-            rp.rgb[3 * out + 0] = (uint8_t)clamp255(cr);
-            rp.rgb[3 * out + 1] = (uint8_t)clamp255(cg);
-            rp.rgb[3 * out + 2] = (uint8_t)clamp255(cb);
+            rp.rgb[3 * (uint64_t)out + 0] = (uint8_t)clamp255(cr);
+            rp.rgb[3 * (uint64_t)out + 1] = (uint8_t)clamp255(cg);
+            rp.rgb[3 * (uint64_t)out + 2] = (uint8_t)clamp255(cb);
         }
-        if (rp.rgb_i32) { rp.rgb_i32[3 * out + 0] = cr; rp.rgb_i32[3 * out + 1] = cg; rp.rgb_i32[3 * out + 2] = cb; }
+        if (rp.rgb_i32) { rp.rgb_i32[3 * (uint64_t)out + 0] = cr; rp.rgb_i32[3 * (uint64_t)out + 1] = cg; rp.rgb_i32[3 * (uint64_t)out + 2] = cb; }
         L.state = ST_FETCH;
         return;
     }
     acc.r += clamp255(cr); acc.g += clamp255(cg); acc.b += clamp255(cb);
     if (s + 1 < (uint32_t)rp.spp) {
-        primary_ray(L, sc, rp, (int)(L.pix & 0xFFFFu), (int)(L.pix >> 16), s + 1);
+        primary_ray(L, sc, rp, (int)(L.pix & 0xFFFFu), (int)(L.pix >> 16), s + 1, rp.n_frames > 1 ? L.out / rp.frame_pixels : 0u);
         start_query(L, sc, PRUNE, root_ref);
         return;
     }
     const int spp = rp.spp;
     if (rp.rgb) {
-        rp.rgb[3 * out + 0] = (uint8_t)((acc.r + spp / 2) / spp);
-        rp.rgb[3 * out + 1] = (uint8_t)((acc.g + spp / 2) / spp);
-        rp.rgb[3 * out + 2] = (uint8_t)((acc.b + spp / 2) / spp);
+        rp.rgb[3 * (uint64_t)out + 0] = (uint8_t)((acc.r + spp / 2) / spp);
+        rp.rgb[3 * (uint64_t)out + 1] = (uint8_t)((acc.g + spp / 2) / spp);
+        rp.rgb[3 * (uint64_t)out + 2] = (uint8_t)((acc.b + spp / 2) / spp);
     }
-    if (rp.rgb_i32) { rp.rgb_i32[3 * out + 0] = acc.r; rp.rgb_i32[3 * out + 1] = acc.g; rp.rgb_i32[3 * out + 2] = acc.b; }
+    if (rp.rgb_i32) { rp.rgb_i32[3 * (uint64_t)out + 0] = acc.r; rp.rgb_i32[3 * (uint64_t)out + 1] = acc.g; rp.rgb_i32[3 * (uint64_t)out + 2] = acc.b; }
     L.state = ST_FETCH;
+}
+
+// Wave-uniform bookkeeping of the persistent loop.
+struct Wave {
+    // the 8x8 block being handed out (pixels cursor..63 are still free), where its top-left pixel lies in the frame
+    // and in the packed-tile output
+    uint32_t cursor, block_x0, block_y0, block_packed0;
+    uint32_t frame;            // which frame of a launch over several frames that block belongs to
+    bool drained;              // every queue ran past its last block
+    uint32_t exhausted;        // queues this wave has seen empty
+    uint32_t blocks_x, per_tile, home_queue;
+    // STATS: rounds the wave ran of each kind and the lanes that took part (kept by lane 0)
+    unsigned long long rounds[3], lane_steps[3];
+};
+
+// The rounds of a wave.  TAIL = false: until every lane is done (returns false) or, with `jobs_possible`, until the
+// first lane is (returns true: the queues are empty, the caller goes on with TAIL = true).  TAIL = true: no lane takes a
+// new pixel any more, lanes without work take lighting jobs; until every lane is done.
+template <bool PRUNE, bool STATS, bool TAIL>
+__device__ __forceinline__ bool wave_loop(Lane &L, PixelSum &acc, Wave &w, const DevScene &sc, const DevRender &rp, const Hot &hot,
+                                          uint32_t *stack, uint32_t stride, const Scratch &scr, Counters &c, uint32_t *pend,
+                                          uint32_t lane, uint64_t gw, bool jobs_possible) {
+    for (;;) {
+        const unsigned long long m_inner = __ballot(L.state == ST_INNER);
+        const unsigned long long m_leaf = __ballot(L.state == ST_LEAF);
+        const unsigned long long m_shade = __ballot(L.state == ST_SHADE);
+        const unsigned long long m_fetch = __ballot(L.state == ST_FETCH);
+        if ((m_inner | m_leaf | m_shade | m_fetch) == 0) return false;  // every lane done
+        const unsigned long long m_idle = ~(m_inner | m_leaf | m_shade | m_fetch);
+        if (!TAIL && jobs_possible && m_idle != 0ull) return true;
+        // wave-uniform choice: the kind of step most lanes wait for (weighted).  With only a
+        // few live lanes left (the end of the frame) every kind that has a lane waiting runs, so
+        // that no lane sits out a round.
+        const int n_inner = __popcll(m_inner), n_leaf = __popcll(m_leaf), n_shade = __popcll(m_shade | m_fetch);
+        const int w_inner = n_inner * hot.w_inner, w_leaf = n_leaf * hot.w_leaf, w_shade = n_shade * hot.w_shade;
+        const bool all_kinds = n_inner + n_leaf + n_shade <= hot.tail_lanes;
+        const bool pick_inner = w_inner >= w_leaf && w_inner >= w_shade;
+        const bool pick_leaf = !pick_inner && w_leaf >= w_shade;
+        if (pick_inner || (all_kinds && n_inner) || n_inner >= hot.also_lanes) {
+            if (STATS && lane == 0) { w.rounds[0]++; w.lane_steps[0] += n_inner; }
+            if (L.state == ST_INNER) inner_step<PRUNE, STATS>(L, hot, stack, stride, c);
+        }
+        if (pick_leaf || (all_kinds && n_leaf) || n_leaf >= hot.also_leaf) {
+            if (STATS) { const int k = __popcll(__ballot(L.state == ST_LEAF)); if (lane == 0) { w.rounds[1]++; w.lane_steps[1] += k; } }
+            if (L.state == ST_LEAF) leaf_step<PRUNE, STATS>(L, hot, stack, stride, c);
+        }
+        if ((!pick_inner && !pick_leaf) || (all_kinds && n_shade) || n_shade >= hot.also_shade) {
+            unsigned long long handed_over = 0ull;
+            if (TAIL) {
+                // closest-hit results that found a surface meet the lanes without work, one pair at a time (rare, and
+                // wave-uniform): the idle lane takes a copy of the result and continues as that hit's lighting job
+                unsigned long long offers = __ballot(L.state == ST_SHADE && (L.path & (1u | kJob)) == 0u && L.best_pos >= 0);
+                if (rp.lighting_jobs == 2) offers = 0ull;               // experiments: the second loop without its jobs
+                unsigned long long idle = m_idle;
+                while (offers != 0ull && idle != 0ull) {
+                    const int a = __builtin_ctzll(offers), h = __builtin_ctzll(idle);
+                    offers &= offers - 1ull;
+                    idle &= idle - 1ull;
+                    handed_over |= 1ull << a;
+                    const double ox = lane_value(L.o.x, a), oy = lane_value(L.o.y, a), oz = lane_value(L.o.z, a);
+                    const double rx = lane_value(L.r.x, a), ry = lane_value(L.r.y, a), rz = lane_value(L.r.z, a);
+                    const double bt = lane_value(L.best_t, a);
+                    const int bp = __builtin_amdgcn_readlane(L.best_pos, a);
+                    const uint32_t pa = (uint32_t)__builtin_amdgcn_readlane((int)L.path, a);
+                    if ((int)lane == h) {
+                        L.o = {ox, oy, oz}; L.r = {rx, ry, rz};
+                        L.best_t = bt; L.best_pos = bp;
+                        L.path = pa | kJob | ((uint32_t)a << 5);
+                        L.sp = 0;
+                        L.state = ST_SHADE;
+                    }
+                }
+                if ((handed_over >> lane) & 1ull) pend[lane] += 1u;     // one more party at work on this lane's pixel
+            }
+            if (STATS) { const int k = __popcll(__ballot(L.state == ST_SHADE)); if (lane == 0) { w.rounds[2]++; w.lane_steps[2] += k; } }
+            if (L.state == ST_SHADE)
+                shade_step<PRUNE, STATS, TAIL>(L, acc, sc, rp, scr, c, hot.root_ref, ((handed_over >> lane) & 1ull) != 0ull, pend, lane);
+            if (TAIL) {
+                if (L.state == ST_FETCH) L.state = ST_DONE;             // the queues are empty
+                continue;
+            }
+            // hand pixels to the lanes without one, in lane order
+            unsigned long long need = __ballot(L.state == ST_FETCH);
+            while (need) {
+                if (w.cursor == 64u && !w.drained) {
+                    // Next 8x8 block: from the queue of this wave's XCD first (its tiles are
+                    // screen neighbours, so the XCD's L2 keeps seeing the same part of the BVH),
+                    // then from the other queues.  Which queue served a block only affects speed.
+                    w.drained = true;
+                    for (uint32_t k = 0; k < rp.n_queues && w.drained; k++) {
+                        const uint32_t q = (w.home_queue + k) % rp.n_queues;
+                        if (w.exhausted & (1u << q)) continue;
+                        const uint32_t q_begin = rp.tile_order[q], q_end = rp.tile_order[q + 1], q_tiles = q_end - q_begin;
+                        // a table that is not one (a caller broke the ordering of the launches that share it) must not
+                        // become an address: the queue then counts as empty
+                        if (q_end < q_begin || q_end > (uint32_t)rp.owned_tiles) { w.exhausted |= 1u << q; continue; }
+                        uint32_t i = 0;
+                        if (lane == 0) i = atomicAdd(rp.work + q * 32u, 1u);
+                        i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+                        // a launch over several frames serves the queue's blocks once per frame, frame after frame
+                        const uint32_t per_frame = q_tiles * w.per_tile;
+                        if (i >= per_frame * (uint32_t)rp.n_frames) { w.exhausted |= 1u << q; continue; }
+                        if (rp.n_frames > 1) { w.frame = i / per_frame; i -= w.frame * per_frame; }
+                        // all wave-uniform: local tile, block inside it, frame position
+                        const uint32_t local_tile = rp.tile_order[9u + q_begin + i / w.per_tile], wb = i % w.per_tile;
+                        const uint32_t tile = (rp.tile_count > 1) ? local_tile * (uint32_t)rp.tile_count + (uint32_t)rp.tile_rank : local_tile;
+                        const uint32_t bx = (wb % w.blocks_x) * 8u, by = (wb / w.blocks_x) * 8u;
+                        w.block_x0 = (tile % (uint32_t)rp.tiles_x) * (uint32_t)rp.tile_w + bx;
+                        w.block_y0 = (tile / (uint32_t)rp.tiles_x) * (uint32_t)rp.tile_h + by;
+                        w.block_packed0 = (local_tile * (uint32_t)rp.tile_h + by) * (uint32_t)rp.tile_w + bx;
+                        w.cursor = 0;
+                        w.drained = false;
+                        if (rp.wave_log && lane == 0) {      // diagnostics: when and where this wave drew its latest block
+                            rp.wave_log[4 * gw + 2] = wall_clock64();
+                            rp.wave_log[4 * gw + 3] = (unsigned long long)w.block_x0 | ((unsigned long long)w.block_y0 << 16) | ((unsigned long long)q << 32);
+                        }
+                    }
+                }
+                if (w.cursor == 64u) {                                  // nothing left anywhere
+                    if (L.state == ST_FETCH) L.state = ST_DONE;
+                    break;
+                }
+                const uint32_t avail = 64u - w.cursor;
+                const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                if (L.state == ST_FETCH && rank < avail) {
+                    const uint32_t in = w.cursor + rank, ix = in & 7u, iy = in >> 3;
+                    const uint32_t col = w.block_x0 + ix, row = w.block_y0 + iy;
+                    // outside the frame or the window: nothing to render, the lane asks again
+                    if ((int)col >= rp.x0 && (int)col < rp.x1 && (int)row >= rp.y0 && (int)row < rp.y1) {
+                        L.pix = col | (row << 16);
+                        L.out = ((rp.layout == RTX_LAYOUT_PACKED_TILES_) ? w.block_packed0 + iy * (uint32_t)rp.tile_w + ix
+                                                                         : row * (uint32_t)rp.W + col) + w.frame * rp.frame_pixels;
+                        acc = {0, 0, 0};
+                        primary_ray(L, sc, rp, (int)col, (int)row, 0, w.frame);
+                        start_query(L, sc, PRUNE, hot.root_ref);
+                    }
+                }
+                const uint32_t n_need = (uint32_t)__popcll(need);
+                w.cursor += n_need < avail ? n_need : avail;
+                // lanes still without a pixel: those the block could not serve and those whose pixel
+                // was outside the window
+                need = __ballot(L.state == ST_FETCH);
+            }
+        }
+    }
 }
 
 template <bool PRUNE, bool STATS>
@@ -710,7 +975,9 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
     const uint32_t stride = 31u - (uint32_t)__builtin_clz(rp.stack_stride);
     // the top of the tree goes into LDS behind the block's stacks
     const uint32_t n_top = sc.n_top_pairs;
-    d2 *top_lds = reinterpret_cast<d2 *>(lds + (uint32_t)(sc.bvh_depth + 1) * rp.stack_stride);
+    d2 *top_lds = reinterpret_cast<d2 *>(lds + (uint32_t)(sc.bvh_depth + 2) * rp.stack_stride);
+    // the row between the stacks and the table: parties at work on each lane's pixel (lighting jobs, see shade_step)
+    uint32_t *pend = lds + (uint32_t)(sc.bvh_depth + 1) * rp.stack_stride + (threadIdx.x & ~63u);
     {
         const d2 *src = reinterpret_cast<const d2 *>(sc.top);
         for (uint32_t i = threadIdx.x; i < n_top * 8u; i += blockDim.x) top_lds[i] = src[i];
@@ -718,11 +985,9 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
     }
     const Hot hot = {sc.nodes, sc.tris, top_lds, n_top ? kTopFlag : 0u, sc.n_point, rp.w_inner, rp.w_leaf, rp.w_shade, rp.tail_lanes, rp.also_lanes, rp.also_leaf, rp.also_shade};
     uint32_t *stack = lds + threadIdx.x;
-    const Scratch scr = {rp.scratch_f64, rp.scratch_i32, rp.scratch_lanes, gw * 64u + lane};
+    const Scratch scr = {rp.scratch_f64, rp.scratch_i32, rp.scratch_lanes, gw * 64u + lane, (uint32_t)rp.depth};
     Counters c;
     if (STATS) for (int i = 0; i < 9; i++) c.v[i] = 0;
-    // STATS: rounds the wave ran of each kind and the lanes that took part (kept by lane 0)
-    unsigned long long rounds[3] = {0, 0, 0}, lane_steps[3] = {0, 0, 0};
 
     Lane L;
     PixelSum acc = {0, 0, 0};
@@ -733,113 +998,40 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
 
     // The launch is persistent: it has only as many waves as the chip holds, and a wave keeps
     // drawing 8x8-pixel blocks from global work queues (`work`, `tile_order`) until they run dry.
-    // `cursor`/`cursor_end` (wave-uniform) are the pixels of the wave's current block not yet
-    // handed to a lane.  A lane whose pixel is finished takes the next one right away, so lanes
-    // behind cheap pixels (background, early misses) do not idle while their neighbours
-    // follow three reflections.
-    // wave-uniform: the 8x8 block being handed out (pixels cursor..63 are still free), where its
-    // top-left pixel lies in the frame and in the packed-tile output
-    uint32_t cursor = 64, block_x0 = 0, block_y0 = 0, block_packed0 = 0;
-    bool drained = false;          // every queue ran past its last block
-    uint32_t exhausted = 0;        // queues this wave has seen empty
-    const uint32_t blocks_x = (uint32_t)rp.tile_w >> 3;
-    const uint32_t per_tile = blocks_x * ((uint32_t)rp.tile_h >> 3);
+    // A lane whose pixel is finished takes the next one right away, so lanes behind cheap pixels
+    // (background, early misses) do not idle while their neighbours follow three reflections.
+    Wave w;
+    w.cursor = 64; w.block_x0 = 0; w.block_y0 = 0; w.block_packed0 = 0; w.frame = 0;
+    w.drained = false;
+    w.exhausted = 0;
+    w.blocks_x = (uint32_t)rp.tile_w >> 3;
+    w.per_tile = w.blocks_x * ((uint32_t)rp.tile_h >> 3);
     // HW_REG_XCC_ID (id 20), bits 3:0: the XCD this wave runs on
-    const uint32_t home_queue = rp.n_queues > 1 ? ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % rp.n_queues : 0u;
+    w.home_queue = rp.n_queues > 1 ? ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % rp.n_queues : 0u;
+    for (int i = 0; i < 3; i++) { w.rounds[i] = 0; w.lane_steps[i] = 0; }
 
-    for (;;) {
-        const unsigned long long m_inner = __ballot(L.state == ST_INNER);
-        const unsigned long long m_leaf = __ballot(L.state == ST_LEAF);
-        const unsigned long long m_shade = __ballot(L.state == ST_SHADE);
-        const unsigned long long m_fetch = __ballot(L.state == ST_FETCH);
-        if ((m_inner | m_leaf | m_shade | m_fetch) == 0) break;         // every lane done
-        // wave-uniform choice: the kind of step most lanes wait for (weighted).  With only a
-        // few live lanes left (the end of the frame) every kind that has a lane waiting runs, so
-        // that no lane sits out a round.
-        const int n_inner = __popcll(m_inner), n_leaf = __popcll(m_leaf), n_shade = __popcll(m_shade | m_fetch);
-        const int w_inner = n_inner * hot.w_inner, w_leaf = n_leaf * hot.w_leaf, w_shade = n_shade * hot.w_shade;
-        const bool all_kinds = n_inner + n_leaf + n_shade <= hot.tail_lanes;
-        const bool pick_inner = w_inner >= w_leaf && w_inner >= w_shade;
-        const bool pick_leaf = !pick_inner && w_leaf >= w_shade;
-        if (pick_inner || (all_kinds && n_inner) || n_inner >= hot.also_lanes) {
-            if (STATS && lane == 0) { rounds[0]++; lane_steps[0] += n_inner; }
-            if (L.state == ST_INNER) inner_step<PRUNE, STATS>(L, hot, stack, stride, c);
-        }
-        if (pick_leaf || (all_kinds && n_leaf) || n_leaf >= hot.also_leaf) {
-            if (STATS) { const int k = __popcll(__ballot(L.state == ST_LEAF)); if (lane == 0) { rounds[1]++; lane_steps[1] += k; } }
-            if (L.state == ST_LEAF) leaf_step<PRUNE, STATS>(L, hot, stack, stride, c);
-        }
-        if ((!pick_inner && !pick_leaf) || (all_kinds && n_shade) || n_shade >= hot.also_shade) {
-            if (STATS) { const int k = __popcll(__ballot(L.state == ST_SHADE)); if (lane == 0) { rounds[2]++; lane_steps[2] += k; } }
-            if (L.state == ST_SHADE) shade_step<PRUNE, STATS>(L, acc, sc, rp, scr, c, hot.root_ref);
-            // hand pixels to the lanes without one, in lane order
-            unsigned long long need = __ballot(L.state == ST_FETCH);
-            while (need) {
-                if (cursor == 64u && !drained) {
-                    // Next 8x8 block: from the queue of this wave's XCD first (its tiles are
-                    // screen neighbours, so the XCD's L2 keeps seeing the same part of the BVH),
-                    // then from the other queues.  Which queue served a block only affects speed.
-                    drained = true;
-                    for (uint32_t k = 0; k < rp.n_queues && drained; k++) {
-                        const uint32_t q = (home_queue + k) % rp.n_queues;
-                        if (exhausted & (1u << q)) continue;
-                        const uint32_t q_begin = rp.tile_order[q], q_end = rp.tile_order[q + 1], q_tiles = q_end - q_begin;
-                        // a table that is not one (a caller broke the ordering of the launches that share it) must not
-                        // become an address: the queue then counts as empty
-                        if (q_end < q_begin || q_end > (uint32_t)rp.owned_tiles) { exhausted |= 1u << q; continue; }
-                        uint32_t i = 0;
-                        if (lane == 0) i = atomicAdd(rp.work + q * 32u, 1u);
-                        i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
-                        if (i >= q_tiles * per_tile) { exhausted |= 1u << q; continue; }
-                        // all wave-uniform: local tile, block inside it, frame position
-                        const uint32_t local_tile = rp.tile_order[9u + q_begin + i / per_tile], wb = i % per_tile;
-                        const uint32_t tile = (rp.tile_count > 1) ? local_tile * (uint32_t)rp.tile_count + (uint32_t)rp.tile_rank : local_tile;
-                        const uint32_t bx = (wb % blocks_x) * 8u, by = (wb / blocks_x) * 8u;
-                        block_x0 = (tile % (uint32_t)rp.tiles_x) * (uint32_t)rp.tile_w + bx;
-                        block_y0 = (tile / (uint32_t)rp.tiles_x) * (uint32_t)rp.tile_h + by;
-                        block_packed0 = (local_tile * (uint32_t)rp.tile_h + by) * (uint32_t)rp.tile_w + bx;
-                        cursor = 0;
-                        drained = false;
-                        if (rp.wave_log && lane == 0) {      // diagnostics: when and where this wave drew its latest block
-                            rp.wave_log[4 * gw + 2] = wall_clock64();
-                            rp.wave_log[4 * gw + 3] = (unsigned long long)block_x0 | ((unsigned long long)block_y0 << 16) | ((unsigned long long)q << 32);
-                        }
-                    }
-                }
-                if (cursor == 64u) {                                    // nothing left anywhere
-                    if (L.state == ST_FETCH) L.state = ST_DONE;
-                    break;
-                }
-                const uint32_t avail = 64u - cursor;
-                const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-                if (L.state == ST_FETCH && rank < avail) {
-                    const uint32_t in = cursor + rank, ix = in & 7u, iy = in >> 3;
-                    const uint32_t col = block_x0 + ix, row = block_y0 + iy;
-                    // outside the frame or the window: nothing to render, the lane asks again
-                    if ((int)col >= rp.x0 && (int)col < rp.x1 && (int)row >= rp.y0 && (int)row < rp.y1) {
-                        L.pix = col | (row << 16);
-                        L.out = (rp.layout == RTX_LAYOUT_PACKED_TILES_) ? block_packed0 + iy * (uint32_t)rp.tile_w + ix
-                                                                        : row * (uint32_t)rp.W + col;
-                        acc = {0, 0, 0};
-                        primary_ray(L, sc, rp, (int)col, (int)row, 0);
-                        start_query(L, sc, PRUNE, hot.root_ref);
-                    }
-                }
-                const uint32_t n_need = (uint32_t)__popcll(need);
-                cursor += n_need < avail ? n_need : avail;
-                // lanes still without a pixel: those the block could not serve and those whose pixel
-                // was outside the window
-                need = __ballot(L.state == ST_FETCH);
-            }
-        }
+    // Lighting jobs.  Once the queues are empty a wave runs on with ever fewer lanes, and what then sets the length of
+    // the launch is the longest pixel: up to depth + 1 closest-hit queries and as many rounds of shadow queries, one
+    // after the other on one lane.  From the moment the wave has lanes without work it therefore runs a second copy of
+    // the loop, in which a lane that comes out of a closest-hit query with a hit hands the lighting of that hit to an
+    // idle lane and follows the reflection at once (see shade_step): the pixel's dependent chain loses its shadow
+    // queries.  One sample per pixel only (a job's marks live in the sample bits of `path`), and only in scenes with
+    // lights.  The steady state runs the first copy, which knows nothing of all this.
+    const bool jobs_possible = rp.spp == 1 && (sc.n_point + sc.n_dir) != 0u && rp.lighting_jobs != 0;
+    if (wave_loop<PRUNE, STATS, false>(L, acc, w, sc, rp, hot, stack, stride, scr, c, pend, lane, gw, jobs_possible)) {
+        // lanes only run out of work when every queue is empty: from here on no lane takes a new pixel, and the
+        // pixels in progress count one party each, their owner's chain
+        pend[lane] = (L.state == ST_DONE) ? 0u : 1u;
+        if (L.state != ST_DONE) scr.waiting() = 0;
+        wave_loop<PRUNE, STATS, true>(L, acc, w, sc, rp, hot, stack, stride, scr, c, pend, lane, gw, jobs_possible);
     }
     if (STATS && rp.stats) {
         for (int i = 0; i < 9; i++)
             if (c.v[i]) atomicAdd(&rp.stats[i], c.v[i]);
         if (lane == 0)
             for (int i = 0; i < 3; i++) {
-                atomicAdd(&rp.stats[9 + i], rounds[i]);
-                atomicAdd(&rp.stats[12 + i], lane_steps[i]);
+                atomicAdd(&rp.stats[9 + i], w.rounds[i]);
+                atomicAdd(&rp.stats[12 + i], w.lane_steps[i]);
             }
     }
     if (rp.wave_log && lane == 0) {

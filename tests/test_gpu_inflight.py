@@ -101,3 +101,25 @@ def test_default_params_select_the_pruned_traversal():
     p = rt.RenderParams()
     rt.lib().rtx_render_params_default(C.byref(p), 64, 48)
     assert (p.traversal, p.depth, p.spp, p.tile_w, p.tile_h) == (rt.TRAVERSAL_PRUNED, 3, 1, 32, 32)
+
+
+def test_lighting_jobs_change_nothing_but_the_schedule(monkeypatch):
+    """At the end of a launch lanes without work take over the lighting of other lanes' surface hits
+    (RTX_LIGHTING_JOBS, on by default).  Frames, ids, t and the census are those of the serial schedule; small frames
+    are almost all tail, which is where the jobs run."""
+    hs = rt.HostScene.load_obj(os.path.join(HERE, "golden", "teapot.obj"), "teapot", no_bvh=True)
+    scene = rt.Scene(hs)
+    for (W, H, kw) in [(64, 64, dict(traversal=rt.TRAVERSAL_PRUNED)), (200, 120, dict(traversal=rt.TRAVERSAL_REFERENCE)),
+                       (96, 96, dict(traversal=rt.TRAVERSAL_PRUNED, depth=5)), (40, 24, dict(traversal=rt.TRAVERSAL_PRUNED, depth=0))]:
+        frames = []
+        for jobs in ("0", "1"):
+            monkeypatch.setenv("RTX_LIGHTING_JOBS", jobs)
+            f = scene.render(W, H, want_stats=True, **kw)
+            st = f.stats.as_dict()
+            st.pop("kernel_ms")
+            for k in ("rounds", "lane_steps"):
+                st.pop(k, None)
+            frames.append((f.rgb, f.hit, st))
+        assert np.array_equal(frames[0][0], frames[1][0]) and np.array_equal(frames[0][1], frames[1][1])
+        assert frames[0][2] == frames[1][2], (frames[0][2], frames[1][2])
+    scene.close()

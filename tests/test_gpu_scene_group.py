@@ -54,7 +54,7 @@ def test_both_exchanges_with_one_member_and_frames_in_flight(teapot, gather):
     with pytest.raises(rt.RtxError):
         group.set_gather(5)
     with pytest.raises(rt.RtxError):
-        group.render(-4, 16)
+        group.submit(rt.make_params(-4, 16), 0)              # refused before any buffer is touched
     group.close()
 
 
