@@ -186,6 +186,24 @@ __device__ __forceinline__ double vmax(double a, double b) {
 // by the caller.
 __device__ __forceinline__ void slab_one_nz(const double *lo, const double *hi, V3 o, V3 r, const RayDiv &d, V3 lim, bool zx,
                                             bool *hit, bool *beyond, double *tnear) {
+#ifdef RTX_EXPERIMENT_APPROX_SLAB
+    // MEASUREMENT ONLY (wrong in the last bit, no fallback): what the frame would cost if every quotient were one
+    // multiplication and the decision compared entries with exits of the OTHER axes only (right on flat boxes)
+    {
+        const double bx1 = (lo[0] - o.x) * d.yx, bx2 = (hi[0] - o.x) * d.yx;
+        const double by1 = (lo[1] - o.y) * d.yy, by2 = (hi[1] - o.y) * d.yy;
+        const double bz1 = (lo[2] - o.z) * d.yz, bz2 = (hi[2] - o.z) * d.yz;
+        double nx = vmin(bx1, bx2), fx = vmax(bx1, bx2);
+        bool x_ok = true;
+        if (zx) { nx = -RTX_INF; fx = RTX_INF; x_ok = (lo[0] - o.x) < 0.0 && (hi[0] - o.x) > 0.0; }
+        const double ny = vmin(by1, by2), fy = vmax(by1, by2), nz = vmin(bz1, bz2), fz = vmax(bz1, bz2);
+        const double mxy = vmin(fx, fy);
+        *tnear = vmax(vmax(nx, ny), nz);
+        *beyond = nx > lim.x || ny > lim.y || nz > lim.z;
+        *hit = x_ok && vmin(mxy, fz) > 0 && nx <= vmin(fy, fz) && ny <= vmin(fx, fz) && nz <= mxy;
+        return;
+    }
+#endif
     const double ax1 = lo[0] - o.x, ax2 = hi[0] - o.x;
     const double qx1 = __builtin_fma(__builtin_fma(-r.x, ax1 * d.yx, ax1), d.yx, ax1 * d.yx);
     const double qx2 = __builtin_fma(__builtin_fma(-r.x, ax2 * d.yx, ax2), d.yx, ax2 * d.yx);
