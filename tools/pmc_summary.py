@@ -26,6 +26,12 @@ if len(sys.argv) >= 5 and "FETCH_SIZE" in out and "WRITE_SIZE" in out:
     table = json.load(open(path)) if os.path.exists(path) else {}
     table[key] = {"FETCH_SIZE_KiB": out["FETCH_SIZE"]["mean_per_dispatch"], "WRITE_SIZE_KiB": out["WRITE_SIZE"]["mean_per_dispatch"],
                   "source": os.path.basename(sys.argv[2])}
-    if "SQ_INSTS_VALU" in out:
-        table[key]["SQ_INSTS_VALU"] = out["SQ_INSTS_VALU"]["mean_per_dispatch"]
+    for name in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU"):
+        if name in out:
+            table[key][name] = out[name]["mean_per_dispatch"]
+    # which kernels the counters were taken from: the hash of the kernel sources this tree's library was built from
+    # (bench.py drops an entry whose hash is not its own library's)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import ray_tracer_amd
+    table[key]["kernel_build"] = ray_tracer_amd.kernel_build()
     json.dump(table, open(path, "w"), indent=1, sort_keys=True)
