@@ -14,7 +14,8 @@
  * Environment: results never depend on it.  For experiments the library reads, per launch,
  * RTX_W_INNER / RTX_W_LEAF / RTX_W_SHADE / RTX_TAIL_LANES / RTX_ALSO_LANES / RTX_ALSO_LEAF /
  * RTX_ALSO_SHADE (the wave scheduler's thresholds), RTX_BLOCKS_PER_CU, RTX_XCD_QUEUES, RTX_MACRO
- * (work distribution) and RTX_WAVE_LOG=<file> (per-wave clock values; synchronous); the loaders
+ * (work distribution), RTX_PIPELINE=staged (rtx_render_device takes the staged pipeline for single-sample frames)
+ * and RTX_WAVE_LOG=<file> (per-wave clock values; synchronous); the loaders
  * print stage times to stderr under RTX_TIMING=1 and size their thread pool by OMP_NUM_THREADS.
  *
  * Threading: a scene handle may be used from any thread.  rtx_render() serialises per
@@ -286,6 +287,18 @@ int rtx_render_device(rtx_scene *scene, const rtx_render_params *p, void *d_rgb_
  * a stream also count the wait for the chip; this does not.  No counterpart in the reference. */
 int rtx_render_device_timed(rtx_scene *scene, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id,
                             void *d_rgb_i32, void *d_t, void *d_stats, void *d_ticks, void *stream);
+
+/* The same frame through the STAGED pipeline: depth + 3 launches on `stream` instead of one.  rtx_render_device()'s
+ * launch keeps a pixel on one lane from its camera ray to its last reflection (Scene::traceRay's recursion,
+ * include/scene.hpp:89-123, as a chain of up to 2 (depth + 1) queries), so a frame launched alone ends with the chip
+ * waiting for its longest pixels.  Here the rays are regrouped between launches: launch l traces the level-l
+ * closest-hit queries of every pixel that still has one, together with the shadow queries of the level l-1 hits
+ * (a hit's lighting and its reflection only meet in the blend, scene.hpp:113,119-122), lanes are refilled query by
+ * query, and a last launch blends each pixel's levels and writes it.  Same pixels, ids, t and counters, bit for bit.
+ * Costs 48 + 24 (depth + 1) bytes of HBM per output pixel (kept with the scene handle per frame in flight).
+ * One sample per pixel only (RTX_ERR_UNSUPPORTED otherwise).  Arguments as rtx_render_device_timed(). */
+int rtx_render_device_staged(rtx_scene *scene, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id,
+                             void *d_rgb_i32, void *d_t, void *d_stats, void *d_ticks, void *stream);
 
 /* Several frames in ONE launch: n_frames (1..8) frames of the scene with the same parameters, frame f into
  * d_rgb_u8 + f * rtx_output_pixels(p) * 3 (d_rgb_i32, nullable: + f * rtx_output_pixels(p) * 12).  `cameras`

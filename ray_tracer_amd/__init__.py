@@ -102,7 +102,7 @@ EXPORTS = (
     "rtx_host_scene_load_obj", "rtx_host_scene_standin", "rtx_host_scene_from_desc", "rtx_host_scene_desc",
     "rtx_host_scene_bvh_depth", "rtx_host_scene_set_camera", "rtx_host_scene_set_lights", "rtx_host_scene_free",
     "rtx_scene_create", "rtx_scene_create_from_host", "rtx_scene_destroy", "rtx_scene_device_bytes",
-    "rtx_render_params_default", "rtx_output_pixels", "rtx_render", "rtx_render_device", "rtx_render_device_timed",
+    "rtx_render_params_default", "rtx_output_pixels", "rtx_render", "rtx_render_device", "rtx_render_device_timed", "rtx_render_device_staged",
     "rtx_untile",
     "rtx_save_ppm", "rtx_save_png", "rtx_selftest_division", "rtx_selftest_pow", "rtx_selftest_sqrt", "rtx_last_error", "rtx_version",
     "rtx_host_scene_load_obj_ex", "rtx_host_scene_standin_ex",
@@ -167,6 +167,7 @@ def lib() -> C.CDLL:
     L.rtx_render.argtypes = [vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]
     L.rtx_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, vp, vp, vp]
     L.rtx_render_device_timed.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, vp, vp, vp, vp]
+    L.rtx_render_device_staged.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, vp, vp, vp, vp]
     L.rtx_render_device_noalloc.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, vp, vp, vp]
     L.rtx_render_begin.argtypes = [vp, C.POINTER(RenderParams), C.c_int32, C.c_int32]
     L.rtx_render_end.argtypes = [vp, C.c_int32, vp, vp]
@@ -468,6 +469,11 @@ class Scene:
         device's 100 MHz clock (duration = [1] - ~[0])."""
         _check(lib().rtx_render_device_timed(self._h, C.byref(params), rgb_u8 or None, hit or None, rgb_i32 or None,
                                              t or None, stats or None, ticks or None, stream or None))
+
+    def render_device_staged(self, params: RenderParams, *, rgb_u8=0, hit=0, rgb_i32=0, t=0, stats=0, ticks=0, stream=0) -> None:
+        """render_device() through the staged pipeline (one launch per level of the reflection chain; one sample per pixel)."""
+        _check(lib().rtx_render_device_staged(self._h, C.byref(params), rgb_u8 or None, hit or None, rgb_i32 or None,
+                                              t or None, stats or None, ticks or None, stream or None))
 
     def render_device_batch(self, params: RenderParams, n_frames: int, *, cameras=None, rgb_u8=0, rgb_i32=0, stats=0, ticks=0, stream=0) -> None:
         """rtx_render_device_batch(): n_frames frames in one launch, consecutive in the output buffers; cameras: optional

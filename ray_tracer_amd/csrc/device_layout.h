@@ -86,6 +86,8 @@ struct DevScene {
     int32_t fast_div_ok;
 };
 
+enum : int32_t { SP_PRIMARY = 0, SP_REFLECT = 1, SP_LIGHT = 2, SP_RESOLVE = 3 };
+
 struct DevRender {
     int32_t W, H, x0, x1, y0, y1;
     int32_t depth, spp;
@@ -120,6 +122,25 @@ struct DevRender {
     uint32_t frame_pixels, frames_pad;
     double cams[8][9];
     int32_t lighting_jobs;              // 1: lanes without work take over the lighting of other lanes' surface hits at the end of a launch
+    // The staged pipeline (rtx_render_device_staged): a frame is a sequence of launches of the same kernel, each of which
+    // serves the queues' blocks once per pass; a lane's unit of work is then ONE query chain of ONE pixel, not the pixel:
+    //   SP_PRIMARY  the camera ray's closest-hit query                                    (launch 0)
+    //   SP_REFLECT  the closest-hit query of level `stage`, for pixels whose level stage-1 hit reflects
+    //   SP_LIGHT    the shadow queries and lighting sum of the level stage-1 hit
+    //   SP_RESOLVE  the blend of a pixel's levels, innermost first, and putPixel           (last launch)
+    // Between launches a pixel lives in the record arrays below, indexed by the pixel's place in the output buffers.
+    int32_t stage, n_passes;
+    int32_t pass_kind[2];
+    uint64_t rec_pixels;                // P: entries per record array (= rtx_output_pixels of the launch)
+    int32_t *rec_pos;                   // [depth + 1][P]  triangle position of the level's hit (written for hits only)
+    // [depth + 1][total_blocks]: bit (row & 7) * 8 + (col & 7) of word b of level l = that pixel of 8x8 block b (local tile x
+    // blocks per tile + block in tile) has a hit at level l.  All zero before a frame; the last launch leaves it so.
+    unsigned long long *hitmask;
+    uint32_t draw_run;                  // blocks a wave draws from a queue with one atomic
+    int32_t refill_min;                 // lanes without work are given new items when this many of them wait
+    double *rec_pt, *rec_ray;           // [2][3][P]       hit point and incoming ray of a level, levels alternate between the halves
+    int32_t *lvl_local;                 // [depth + 1][3][P]  localColor of a level (colour x lighting, truncated: scene.hpp:113)
+    double *lvl_refl;                   // [depth + 1][P]  reflectivity of the level's triangle
     unsigned long long *wave_log;       // diagnostics, or NULL: per wave {start, end, latest block drawn} in 100 MHz ticks and that block (x0 | y0 << 16 | queue << 32)
     unsigned long long *ticks;          // {earliest block start, latest block end} in 100 MHz ticks, or NULL
 };

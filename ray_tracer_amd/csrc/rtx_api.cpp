@@ -45,6 +45,11 @@ struct rtx_scene {
     std::mutex slot_lock;
     // launch geometry whose work-queue table each slot's scratch holds (see tile_order_kernel)
     std::vector<int64_t> slot_key[kSlots];
+    // record arrays of the staged pipeline (a pixel's state between the launches of one frame), per slot, grown on demand
+    void *d_records[kSlots] = {};
+    uint64_t record_bytes[kSlots] = {};
+    bool records_dirty[kSlots] = {};
+    std::vector<int64_t> mask_key[kSlots];
     // rtx_render()'s output buffers (device, and pinned host memory for the way back) and events, kept between calls
     void *d_out_rgb = nullptr, *d_out_hit = nullptr, *d_out_stats = nullptr, *h_out_rgb = nullptr, *h_out_hit = nullptr;
     uint64_t out_rgb_bytes = 0, out_hit_bytes = 0;
@@ -691,6 +696,7 @@ void rtx_scene_destroy(rtx_scene *sc) {
     (void)hipFree(sc->d_top);
     for (int k = 0; k < rtx_scene::kSlots; k++) {
         (void)hipFree(sc->d_scratch[k]);
+        (void)hipFree(sc->d_records[k]);
         if (sc->slot_done[k]) (void)hipEventDestroy(sc->slot_done[k]);
     }
     (void)hipFree(sc->d_out_rgb);
@@ -851,10 +857,44 @@ static int plan_frames(rtx_scene *sc, const rtx_render_params *p, int32_t n_fram
     return RTX_OK;
 }
 
+// The launches of one staged frame (see the staged pipeline in rtx_kernels.hip): launch 0 traces the camera rays, launch l
+// (1..depth) the level-l reflections and the lighting of the level l-1 hits, launch depth+1 the lighting of the last level,
+// launch depth+2 blends and writes the pixels.  One stream, one after the other.
+static int launch_staged_frame(rtx_scene *sc, LaunchPlan &plan, void *records, uint64_t pixels, bool stats, hipStream_t st) {
+    rtx::DevRender &r = plan.r;
+    const uint64_t levels = (uint64_t)r.depth + 1, P = pixels;
+    r.rec_pixels = P;
+    r.hitmask = (unsigned long long *)records;
+    r.rec_pt = (double *)((char *)records + (rtx::staged_mask_bytes(r.total_blocks, r.depth) + 255) / 256 * 256);
+    r.rec_ray = r.rec_pt + 2 * 3 * P;
+    r.lvl_refl = r.rec_ray + 2 * 3 * P;
+    r.rec_pos = (int32_t *)(r.lvl_refl + levels * P);
+    r.lvl_local = r.rec_pos + levels * P;
+    const char *run = getenv("RTX_STAGED_RUN");
+    r.draw_run = (uint32_t)std::min(64, std::max(1, run && *run ? atoi(run) : 1));
+    const char *refill = getenv("RTX_STAGED_REFILL");
+    r.refill_min = std::min(64, std::max(1, refill && *refill ? atoi(refill) : 8));
+    const char *only = getenv("RTX_STAGED_ONLY");        // experiments: stop after this launch (leaves the masks dirty)
+    const int32_t last = only && *only ? std::min(atoi(only), r.depth + 2) : r.depth + 2;
+    for (int32_t l = 0; l <= last; l++) {
+        r.stage = l;
+        if (l == 0) { r.n_passes = 1; r.pass_kind[0] = rtx::SP_PRIMARY; }
+        else if (l <= r.depth) { r.n_passes = 2; r.pass_kind[0] = rtx::SP_REFLECT; r.pass_kind[1] = rtx::SP_LIGHT; }
+        else if (l == r.depth + 1) { r.n_passes = 1; r.pass_kind[0] = rtx::SP_LIGHT; }
+        else { r.n_passes = 1; r.pass_kind[0] = rtx::SP_RESOLVE; }
+        if (r.n_passes == 1) r.pass_kind[1] = r.pass_kind[0];
+        if ((uint64_t)r.total_blocks * (uint64_t)r.n_passes + 64 >= (1ull << 26)) return fail(RTX_ERR_UNSUPPORTED, "more than 2^32 pixels in one launch");
+        HIP_TRY(rtx::launch_render(sc->dev, r, plan.pruned, stats, plan.block, (uint32_t)plan.grid_blocks, st, true));
+    }
+    return RTX_OK;
+}
+
 static int render_device_timed_impl(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id, void *d_rgb_i32, void *d_t,
-                            void *d_stats, void *d_ticks, void *stream, int32_t n_frames = 1, const double *cameras = nullptr) {
+                            void *d_stats, void *d_ticks, void *stream, int32_t n_frames = 1, const double *cameras = nullptr,
+                            bool staged = false) {
     LaunchPlan plan;
     if (int rc = plan_render(sc, p, d_rgb_u8, d_hit_id, d_rgb_i32, d_t, d_stats, d_ticks, &plan)) return rc;
+    if (staged && plan.r.spp != 1) return fail(RTX_ERR_UNSUPPORTED, "the staged pipeline renders one sample per pixel; use rtx_render_device");
     if (plan.grid_blocks == 0) return RTX_OK;
     if (n_frames != 1 || cameras)
         if (int rc = plan_frames(sc, p, n_frames, cameras, &plan)) return rc;
@@ -903,7 +943,28 @@ static int render_device_timed_impl(rtx_scene *sc, const rtx_render_params *p, v
         HIP_TRY(hipMemset(log.p, 0, n_waves * 32));
         r.wave_log = (unsigned long long *)log.p;
     }
-    HIP_TRY(rtx::launch_render(sc->dev, r, plan.pruned, d_stats != nullptr, plan.block, (uint32_t)plan.grid_blocks, st));
+    if (staged) {
+        const uint64_t pixels = rtx_output_pixels(p), masks = (rtx::staged_mask_bytes(r.total_blocks, r.depth) + 255) / 256 * 256;
+        const uint64_t want = masks + rtx::staged_record_bytes(pixels, r.depth);
+        if (want > sc->record_bytes[slot]) {
+            if (sc->d_records[slot]) HIP_TRY(hipFree(sc->d_records[slot]));   // waits for launches still using it
+            sc->d_records[slot] = nullptr;
+            sc->record_bytes[slot] = 0;
+            HIP_TRY(hipMalloc(&sc->d_records[slot], want));
+            sc->record_bytes[slot] = want;
+            sc->records_dirty[slot] = true;
+        }
+        // The hit masks must be zero before a frame.  A frame's last launch leaves them so; only new memory, a frame whose
+        // launches did not all go out, or a change of geometry (the masks' place and count move with it) needs the fill.
+        const std::vector<int64_t> mask_key = {(int64_t)r.total_blocks, r.depth};
+        if (sc->records_dirty[slot] || mask_key != sc->mask_key[slot]) HIP_TRY(hipMemsetAsync(sc->d_records[slot], 0, masks, st));
+        sc->mask_key[slot] = mask_key;
+        sc->records_dirty[slot] = true;
+        if (int rc = launch_staged_frame(sc, plan, sc->d_records[slot], pixels, d_stats != nullptr, st)) return rc;
+        sc->records_dirty[slot] = getenv("RTX_STAGED_ONLY") != nullptr;
+    } else {
+        HIP_TRY(rtx::launch_render(sc->dev, r, plan.pruned, d_stats != nullptr, plan.block, (uint32_t)plan.grid_blocks, st));
+    }
     HIP_TRY(hipEventRecord(sc->slot_done[slot], st));
     if (log.p) {
         std::vector<unsigned long long> h(n_waves * 4);
@@ -1279,12 +1340,20 @@ int rtx_scene_create_with_builder(const rtx_scene_desc *desc, int32_t builder, r
 
 int rtx_render_device_timed(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id, void *d_rgb_i32, void *d_t,
                             void *d_stats, void *d_ticks, void *stream) {
-    return guarded([&]() -> int { return render_device_timed_impl(sc, p, d_rgb_u8, d_hit_id, d_rgb_i32, d_t, d_stats, d_ticks, stream); });
+    // RTX_PIPELINE=staged (experiments, and the test suite's second pass): single-sample frames take the staged pipeline
+    const char *pipe = getenv("RTX_PIPELINE");
+    const bool staged = pipe && !strcmp(pipe, "staged") && p && p->spp <= 1;
+    return guarded([&]() -> int { return render_device_timed_impl(sc, p, d_rgb_u8, d_hit_id, d_rgb_i32, d_t, d_stats, d_ticks, stream, 1, nullptr, staged); });
 }
 
 int rtx_render_device_batch(rtx_scene *sc, const rtx_render_params *p, int32_t n_frames, const double *cameras, void *d_rgb_u8,
                             void *d_rgb_i32, void *d_stats, void *d_ticks, void *stream) {
     return guarded([&]() -> int { return render_device_timed_impl(sc, p, d_rgb_u8, nullptr, d_rgb_i32, nullptr, d_stats, d_ticks, stream, n_frames, cameras); });
+}
+
+int rtx_render_device_staged(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id, void *d_rgb_i32, void *d_t,
+                             void *d_stats, void *d_ticks, void *stream) {
+    return guarded([&]() -> int { return render_device_timed_impl(sc, p, d_rgb_u8, d_hit_id, d_rgb_i32, d_t, d_stats, d_ticks, stream, 1, nullptr, true); });
 }
 
 int rtx_render_device_noalloc(rtx_scene *sc, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id, void *d_rgb_i32, void *d_t,

@@ -62,8 +62,16 @@ hipError_t launch_tile_order(uint32_t *d_order, const DevRender &rp, int macro, 
 
 // 256-thread blocks of the render kernel one CU keeps resident (= its waves per SIMD)
 int render_blocks_per_cu();
+// staged: one launch of the staged pipeline (rp.stage, rp.n_passes, rp.pass_kind and the record arrays set)
 hipError_t launch_render(const DevScene &sc, const DevRender &rp, bool prune, bool stats, uint32_t block_threads,
-                         uint32_t grid_blocks, hipStream_t st);
+                         uint32_t grid_blocks, hipStream_t st, bool staged = false);
+// bytes of a staged frame's record arrays for P output pixels (DevRender::rec_pos ... lvl_refl)
+inline uint64_t staged_record_bytes(uint64_t P, int32_t depth) {
+    const uint64_t levels = (uint64_t)depth + 1;
+    return P * (levels * 4 + 2 * 2 * 3 * 8 + levels * 3 * 4 + levels * 8);
+}
+// and of its per-block hit masks (DevRender::hitmask), which sit in front of the records
+inline uint64_t staged_mask_bytes(uint64_t total_blocks, int32_t depth) { return ((uint64_t)depth + 1) * total_blocks * 8; }
 hipError_t launch_divtest(uint64_t seed, uint64_t n, unsigned long long *d_mismatches, hipStream_t st);
 hipError_t launch_sqrttest(const double *d_x, double *d_out, uint64_t n, hipStream_t st);
 hipError_t launch_powtest(const double *d_x, const int32_t *d_e, double *d_out, uint64_t n, hipStream_t st);

@@ -374,6 +374,7 @@ struct Lane {
     uint32_t path;
     uint32_t pix;        // the pixel: column | row << 16
     uint32_t out;        // its index in the output buffers (row-major or packed-tile layout)
+    uint32_t blk;        // staged launches: the pixel's 8x8 block (index into DevRender::hitmask)
 };
 
 __device__ __forceinline__ uint32_t path_kind(uint32_t p) { return p & 1u; }
@@ -835,6 +836,42 @@ struct Wave {
     unsigned long long rounds[3], lane_steps[3];
 };
 
+// The next 8x8 block for a wave whose current one is used up: from the queue of this wave's XCD first (its tiles are
+// screen neighbours, so the XCD's L2 keeps seeing the same part of the BVH), then from the other queues.  Which queue
+// served a block only affects speed.  Every queue hands its blocks out `n_serve` times over, one whole pass after the
+// other (the frames of a launch over several frames, the passes of a staged launch); w.frame says which pass the block
+// belongs to.  Leaves w.drained set when every queue has run past its last block.
+__device__ __forceinline__ void draw_block(Wave &w, const DevRender &rp, uint32_t n_serve, uint32_t lane, uint64_t gw) {
+    w.drained = true;
+    for (uint32_t k = 0; k < rp.n_queues && w.drained; k++) {
+        const uint32_t q = (w.home_queue + k) % rp.n_queues;
+        if (w.exhausted & (1u << q)) continue;
+        const uint32_t q_begin = rp.tile_order[q], q_end = rp.tile_order[q + 1], q_tiles = q_end - q_begin;
+        // a table that is not one (a caller broke the ordering of the launches that share it) must not
+        // become an address: the queue then counts as empty
+        if (q_end < q_begin || q_end > (uint32_t)rp.owned_tiles) { w.exhausted |= 1u << q; continue; }
+        uint32_t i = 0;
+        if (lane == 0) i = atomicAdd(rp.work + q * 32u, 1u);
+        i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+        const uint32_t per_pass = q_tiles * w.per_tile;
+        if (i >= per_pass * n_serve) { w.exhausted |= 1u << q; continue; }
+        if (n_serve > 1) { w.frame = i / per_pass; i -= w.frame * per_pass; }
+        // all wave-uniform: local tile, block inside it, frame position
+        const uint32_t local_tile = rp.tile_order[9u + q_begin + i / w.per_tile], wb = i % w.per_tile;
+        const uint32_t tile = (rp.tile_count > 1) ? local_tile * (uint32_t)rp.tile_count + (uint32_t)rp.tile_rank : local_tile;
+        const uint32_t bx = (wb % w.blocks_x) * 8u, by = (wb / w.blocks_x) * 8u;
+        w.block_x0 = (tile % (uint32_t)rp.tiles_x) * (uint32_t)rp.tile_w + bx;
+        w.block_y0 = (tile / (uint32_t)rp.tiles_x) * (uint32_t)rp.tile_h + by;
+        w.block_packed0 = (local_tile * (uint32_t)rp.tile_h + by) * (uint32_t)rp.tile_w + bx;
+        w.cursor = 0;
+        w.drained = false;
+        if (rp.wave_log && lane == 0) {      // diagnostics: when and where this wave drew its latest block
+            rp.wave_log[4 * gw + 2] = wall_clock64();
+            rp.wave_log[4 * gw + 3] = (unsigned long long)w.block_x0 | ((unsigned long long)w.block_y0 << 16) | ((unsigned long long)q << 32);
+        }
+    }
+}
+
 // The rounds of a wave.  TAIL = false: until every lane is done (returns false) or, with `jobs_possible`, until the
 // first lane is (returns true: the queues are empty, the caller goes on with TAIL = true).  TAIL = true: no lane takes a
 // new pixel any more, lanes without work take lighting jobs; until every lane is done.
@@ -904,40 +941,7 @@ __device__ __forceinline__ bool wave_loop(Lane &L, PixelSum &acc, Wave &w, const
             // hand pixels to the lanes without one, in lane order
             unsigned long long need = __ballot(L.state == ST_FETCH);
             while (need) {
-                if (w.cursor == 64u && !w.drained) {
-                    // Next 8x8 block: from the queue of this wave's XCD first (its tiles are
-                    // screen neighbours, so the XCD's L2 keeps seeing the same part of the BVH),
-                    // then from the other queues.  Which queue served a block only affects speed.
-                    w.drained = true;
-                    for (uint32_t k = 0; k < rp.n_queues && w.drained; k++) {
-                        const uint32_t q = (w.home_queue + k) % rp.n_queues;
-                        if (w.exhausted & (1u << q)) continue;
-                        const uint32_t q_begin = rp.tile_order[q], q_end = rp.tile_order[q + 1], q_tiles = q_end - q_begin;
-                        // a table that is not one (a caller broke the ordering of the launches that share it) must not
-                        // become an address: the queue then counts as empty
-                        if (q_end < q_begin || q_end > (uint32_t)rp.owned_tiles) { w.exhausted |= 1u << q; continue; }
-                        uint32_t i = 0;
-                        if (lane == 0) i = atomicAdd(rp.work + q * 32u, 1u);
-                        i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
-                        // a launch over several frames serves the queue's blocks once per frame, frame after frame
-                        const uint32_t per_frame = q_tiles * w.per_tile;
-                        if (i >= per_frame * (uint32_t)rp.n_frames) { w.exhausted |= 1u << q; continue; }
-                        if (rp.n_frames > 1) { w.frame = i / per_frame; i -= w.frame * per_frame; }
-                        // all wave-uniform: local tile, block inside it, frame position
-                        const uint32_t local_tile = rp.tile_order[9u + q_begin + i / w.per_tile], wb = i % w.per_tile;
-                        const uint32_t tile = (rp.tile_count > 1) ? local_tile * (uint32_t)rp.tile_count + (uint32_t)rp.tile_rank : local_tile;
-                        const uint32_t bx = (wb % w.blocks_x) * 8u, by = (wb / w.blocks_x) * 8u;
-                        w.block_x0 = (tile % (uint32_t)rp.tiles_x) * (uint32_t)rp.tile_w + bx;
-                        w.block_y0 = (tile / (uint32_t)rp.tiles_x) * (uint32_t)rp.tile_h + by;
-                        w.block_packed0 = (local_tile * (uint32_t)rp.tile_h + by) * (uint32_t)rp.tile_w + bx;
-                        w.cursor = 0;
-                        w.drained = false;
-                        if (rp.wave_log && lane == 0) {      // diagnostics: when and where this wave drew its latest block
-                            rp.wave_log[4 * gw + 2] = wall_clock64();
-                            rp.wave_log[4 * gw + 3] = (unsigned long long)w.block_x0 | ((unsigned long long)w.block_y0 << 16) | ((unsigned long long)q << 32);
-                        }
-                    }
-                }
+                if (w.cursor == 64u && !w.drained) draw_block(w, rp, (uint32_t)rp.n_frames, lane, gw);
                 if (w.cursor == 64u) {                                  // nothing left anywhere
                     if (L.state == ST_FETCH) L.state = ST_DONE;
                     break;
@@ -967,7 +971,315 @@ __device__ __forceinline__ bool wave_loop(Lane &L, PixelSum &acc, Wave &w, const
     }
 }
 
+// ---------------------------------------------------------------------------------
+// The staged pipeline: the same steps, regrouped.  In render_kernel's own loop a lane owns a pixel from its camera
+// ray to its last reflection, up to 2 (depth + 1) queries one after the other, and the launch ends when the longest
+// such chain does.  Here the frame is depth + 3 launches (DevRender::stage), and between launches every pixel's state
+// lies in memory, so that each launch hands out single queries: launch l traces the level-l closest-hit queries of all
+// pixels that still have one (and, in a pass of its own, the lighting of their level l-1 hits, whose shadow queries do
+// not depend on the reflection: scene.hpp:113 and :119-121 only meet in the blend).  A wave's lanes then run rays of one
+// kind -- all reflections of one level, or all shadow rays, which share their direction for a directional light -- lanes
+// take the next query of the wave's block as soon as theirs ends, and the longest dependent chain of a launch is one
+// query (or one hit's shadow queries).  Which pixels of an 8x8 block have a hit at a level is a 64-bit mask per block and
+// level (DevRender::hitmask), set by the lanes that find the hits; the next launch reads a block's mask once and hands
+// out exactly those pixels, so a block or pixel whose chain has ended costs nothing later.  Results are the fused
+// kernel's, bit for bit: the same operations on the same values, the hit point and ray of a level travel as the doubles
+// they are.
+
+// The lighting of a level is complete: its localColor and reflectivity go to the pixel's records.
+__device__ __forceinline__ void stage_level_done(const DevScene &sc, const DevRender &rp, const Scratch &scr, uint32_t lv, uint64_t out) {
+    // Color * double truncates each channel (color.hpp:47-53); the reflectivity decides in the next launch and in the blend
+    const uint64_t P = rp.rec_pixels;
+    const int32_t pos = scr.i(0);
+    const DevMat &mt = sc.mats[pos];
+    const double total = scr.f(3);
+    int32_t *local = rp.lvl_local + (uint64_t)lv * 3u * P + out;
+    local[0] = to_int(mt.color[0] * total); local[P] = to_int(mt.color[1] * total); local[2 * P] = to_int(mt.color[2] * total);
+    rp.lvl_refl[(uint64_t)lv * P + out] = mt.reflectivity;
+}
+
+__device__ __forceinline__ void put_pixel(const DevRender &rp, uint64_t out, int cr, int cg, int cb) {
+    // putPixel (src/main.cpp:90-94) + the clamp of saveCanvas (src/main.cpp:107)
+    if (rp.rgb) {
+        rp.rgb[3 * out + 0] = (uint8_t)clamp255(cr);
+        rp.rgb[3 * out + 1] = (uint8_t)clamp255(cg);
+        rp.rgb[3 * out + 2] = (uint8_t)clamp255(cb);
+    }
+    if (rp.rgb_i32) { rp.rgb_i32[3 * out + 0] = cr; rp.rgb_i32[3 * out + 1] = cg; rp.rgb_i32[3 * out + 2] = cb; }
+}
+
+// A finished query of a staged launch.  Leaves the lane with the next shadow query of the same hit or without work.
 template <bool PRUNE, bool STATS>
+__device__ __forceinline__ void stage_finish(Lane &L, const DevScene &sc, const DevRender &rp, const Scratch &scr, Counters &c,
+                                             uint32_t root_ref) {
+    const uint64_t P = rp.rec_pixels, out = L.out;
+    const uint32_t kind = path_kind(L.path), lv = path_d(L.path);
+    if (kind == 0) {
+        // Scene::traceRay after the closest-hit query (scene.hpp:97-111): the level's record
+        if (STATS) c.v[lv == 0 ? C_PRIMARY : C_REFLECTION]++;
+        if (lv == 0 && (rp.hit || rp.t)) {
+            const uint64_t k = (uint64_t)(L.pix >> 16) * (uint64_t)rp.W + (uint64_t)(L.pix & 0xFFFFu);
+            if (rp.hit) rp.hit[k] = (L.best_pos >= 0) ? (int32_t)sc.tris[L.best_pos].orig_id : -1;
+            if (rp.t) rp.t[k] = L.best_t;
+        }
+        if (L.best_pos >= 0) {
+            if (STATS) c.v[C_CLOSEST]++;
+            const V3 pt = add(L.o, smul(L.best_t, L.r));               // point, scene.hpp:105
+            double *rec_pt = rp.rec_pt + (uint64_t)(lv & 1u) * 3u * P + out, *rec_ray = rp.rec_ray + (uint64_t)(lv & 1u) * 3u * P + out;
+            rec_pt[0] = pt.x; rec_pt[P] = pt.y; rec_pt[2 * P] = pt.z;
+            rec_ray[0] = L.r.x; rec_ray[P] = L.r.y; rec_ray[2 * P] = L.r.z;
+            rp.rec_pos[(uint64_t)lv * P + out] = L.best_pos;
+            // the pixel's bit in its block's mask of this level: (row & 7) * 8 + (col & 7), blocks are 8-aligned in the frame
+            const uint32_t bit = ((L.pix >> 13) & 0x38u) | (L.pix & 7u);
+            (void)__hip_atomic_fetch_or(rp.hitmask + (uint64_t)lv * rp.total_blocks + L.blk, 1ull << bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (lv == 0) {
+            put_pixel(rp, out, sc.bg[0], sc.bg[1], sc.bg[2]);           // backgroundColor, scene.hpp:101-103: the pixel is done
+        }
+        L.state = ST_FETCH;
+        return;
+    }
+    // the rest of Scene::computeLighting (scene.hpp:159-182) with light = r, point = o
+    uint32_t li = path_li(L.path);
+    if (STATS) { c.v[C_SHADOW]++; if (L.best_pos >= 0) c.v[C_OCCLUDED]++; }
+    if (L.best_pos < 0) {
+        const int32_t pos = scr.i(0);
+        const V3 n = ld3(sc.tris[pos].n);
+        const V3 v = {scr.f(0), scr.f(1), scr.f(2)};
+        const int spec = sc.mats[pos].specularity;
+        const double intensity = sc.lights[li].intensity;
+        double term = 0.0;
+        const double nl = dot(n, L.r);
+        if (nl > 0.0) term += intensity * (nl / (mag(n) * mag(L.r)));
+        __builtin_amdgcn_sched_barrier(0);
+        if (spec != -1) {
+            const V3 R = reflect_ray(L.r, n);
+            const double rv = dot(R, v);
+            if (rv > 0) {
+                const double cosv = rv / (mag(R) * mag(v));
+                term += intensity * ((spec == 1) ? cosv : general_pow(cosv, (double)spec));
+            }
+        }
+        scr.f(3) += term;
+    }
+    li++;
+    if (li < sc.n_point + sc.n_dir) {
+        // computeTotalLighting (scene.hpp:130-142): point lights first, then directional ones
+        const V3 lvec = ld3(sc.lights[li].v);
+        L.r = (li < sc.n_point) ? sub(lvec, L.o) : lvec;
+        L.path = make_path(1, lv, 0, li);
+        start_query(L, sc, PRUNE, root_ref);
+        return;
+    }
+    stage_level_done(sc, rp, scr, lv, out);
+    L.state = ST_FETCH;
+}
+
+// A lane without work has been given a pixel of the wave's block (L.pix, L.out, L.blk set): start that pixel's item of
+// this pass.  Leaves the lane in ST_INNER (a query runs) or in ST_FETCH (nothing to trace: it asks again).
+template <bool PRUNE, bool STATS>
+__device__ __forceinline__ void stage_begin(Lane &L, const DevScene &sc, const DevRender &rp, const Scratch &scr, uint32_t root_ref,
+                                            int32_t kind) {
+    const uint64_t P = rp.rec_pixels, out = L.out;
+    const uint32_t stage = (uint32_t)rp.stage;
+    if (kind == SP_PRIMARY) {
+        primary_ray(L, sc, rp, (int)(L.pix & 0xFFFFu), (int)(L.pix >> 16), 0, 0);
+        start_query(L, sc, PRUNE, root_ref);
+        return;
+    }
+    if (kind == SP_REFLECT || kind == SP_LIGHT) {
+        // the level stage-1 hit of this pixel (its bit is set in the block's mask of that level)
+        const uint32_t from = stage - 1u;
+        const double *rec_pt = rp.rec_pt + (uint64_t)(from & 1u) * 3u * P + out, *rec_ray = rp.rec_ray + (uint64_t)(from & 1u) * 3u * P + out;
+        const int32_t pos = rp.rec_pos[(uint64_t)from * P + out];
+        L.o = {rec_pt[0], rec_pt[P], rec_pt[2 * P]};
+        const V3 v = muls(V3{rec_ray[0], rec_ray[P], rec_ray[2 * P]}, -1.0);     // -ray, vector3.hpp:108-110
+        if (kind == SP_REFLECT) {
+            // scene.hpp:115-121: the hit reflects unless its reflectivity is negative (the recursion depth is the host's
+            // business: it launches no such pass beyond `depth`)
+            const double refl = sc.mats[pos].reflectivity;
+            const V3 n = ld3(sc.tris[pos].n);
+            if (refl < 0) return;
+            L.r = reflect_ray(v, n);                                    // scene.hpp:119
+            L.path = make_path(0, stage, 0, 0);
+            start_query(L, sc, PRUNE, root_ref);
+            return;
+        }
+        scr.f(0) = v.x; scr.f(1) = v.y; scr.f(2) = v.z;
+        scr.f(3) = sc.ambient;                                          // scene.hpp:128
+        scr.i(0) = pos;
+        if (sc.n_point + sc.n_dir == 0u) {
+            stage_level_done(sc, rp, scr, from, out);
+            return;
+        }
+        const V3 lvec = ld3(sc.lights[0].v);
+        L.r = (sc.n_point != 0u) ? sub(lvec, L.o) : lvec;
+        L.path = make_path(1, from, 0, 0);
+        start_query(L, sc, PRUNE, root_ref);
+        return;
+    }
+    // SP_RESOLVE (pixels whose camera ray hit): walk the pixel's levels down to where its chain ended, then blend back
+    // up (localColor * (1 - reflectivity) + reflectedColor * reflectivity, scene.hpp:122), innermost first.  Level l + 1
+    // was a hit iff the pixel's bit is set in the block's mask of that level.
+    const uint32_t bit = ((L.pix >> 13) & 0x38u) | (L.pix & 7u);
+    int cr = 0, cg = 0, cb = 0;
+    uint32_t levels = 0;
+    for (;; levels++) {
+        const int32_t *local = rp.lvl_local + (uint64_t)levels * 3u * P + out;
+        cr = local[0]; cg = local[P]; cb = local[2 * P];
+        if (levels == (uint32_t)rp.depth || rp.lvl_refl[(uint64_t)levels * P + out] < 0) break;   // scene.hpp:115-117
+        if (!((rp.hitmask[(uint64_t)(levels + 1u) * rp.total_blocks + L.blk] >> bit) & 1ull)) {
+            cr = sc.bg[0]; cg = sc.bg[1]; cb = sc.bg[2];                // the reflected ray missed: backgroundColor, scene.hpp:101-103
+            levels++;
+            break;
+        }
+    }
+    while (levels > 0) {
+        levels--;
+        const int32_t *local = rp.lvl_local + (uint64_t)levels * 3u * P + out;
+        const int lr = local[0], lg = local[P], lb = local[2 * P];
+        const double refl = rp.lvl_refl[(uint64_t)levels * P + out];
+        const double keep = 1 - refl;
+        // int + int wraps on both machines
+        cr = (int)((uint32_t)to_int(lr * keep) + (uint32_t)to_int(cr * refl));
+        cg = (int)((uint32_t)to_int(lg * keep) + (uint32_t)to_int(cg * refl));
+        cb = (int)((uint32_t)to_int(lb * keep) + (uint32_t)to_int(cb * refl));
+    }
+    put_pixel(rp, out, cr, cg, cb);
+}
+
+// Wave-uniform bookkeeping of a staged launch's hand-out, beside Wave.
+struct Run {
+    uint32_t next, end, queue;     // blocks next..end-1 of `queue` are this wave's (one atomic draws several blocks)
+    uint32_t blk;                  // the current block's index in the launch (local tile * blocks per tile + block in tile)
+    unsigned long long mask;       // its pixels that still wait for a lane in this pass
+};
+
+// The next block with work for a wave whose current one is used up (run.mask == 0).  A draw takes rp.draw_run
+// consecutive blocks of one queue with one atomic -- a pass over a frame is some 10^5 blocks, and a queue's counter is one
+// address for the whole chip -- and a block whose mask of the level is empty is passed over at the cost of one scalar load.
+__device__ __forceinline__ void draw_staged(Wave &w, Run &run, const DevRender &rp, uint32_t lane, uint64_t gw) {
+    for (;;) {
+        if (run.next == run.end) {
+            w.drained = true;
+            for (uint32_t k = 0; k < rp.n_queues && w.drained; k++) {
+                const uint32_t q = (w.home_queue + k) % rp.n_queues;
+                if (w.exhausted & (1u << q)) continue;
+                const uint32_t q_begin = rp.tile_order[q], q_end = rp.tile_order[q + 1];
+                if (q_end < q_begin || q_end > (uint32_t)rp.owned_tiles) { w.exhausted |= 1u << q; continue; }
+                const uint32_t total = (q_end - q_begin) * w.per_tile * (uint32_t)rp.n_passes;
+                uint32_t i = 0;
+                if (lane == 0) i = atomicAdd(rp.work + q * 32u, rp.draw_run);
+                i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+                if (i >= total) { w.exhausted |= 1u << q; continue; }
+                run.queue = q;
+                run.next = i;
+                run.end = (total - i < rp.draw_run) ? total : i + rp.draw_run;
+                w.drained = false;
+            }
+            if (w.drained) return;
+        }
+        const uint32_t q_begin = rp.tile_order[run.queue], per_pass = (rp.tile_order[run.queue + 1] - q_begin) * w.per_tile;
+        uint32_t i = run.next++;
+        w.frame = i / per_pass;                                  // the pass
+        i -= w.frame * per_pass;
+        const uint32_t local_tile = rp.tile_order[9u + q_begin + i / w.per_tile], wb = i % w.per_tile;
+        run.blk = local_tile * w.per_tile + wb;
+        const int32_t kind = rp.pass_kind[w.frame];
+        // which pixels of the block have an item in this pass: every pixel for the camera rays, else the hits of the
+        // level this launch continues (the blend: the hits of the camera rays)
+        run.mask = kind == SP_PRIMARY ? ~0ull : rp.hitmask[(uint64_t)(kind == SP_RESOLVE ? 0u : (uint32_t)rp.stage - 1u) * rp.total_blocks + run.blk];
+        if (run.mask == 0ull) continue;
+        const uint32_t tile = (rp.tile_count > 1) ? local_tile * (uint32_t)rp.tile_count + (uint32_t)rp.tile_rank : local_tile;
+        const uint32_t bx = (wb % w.blocks_x) * 8u, by = (wb / w.blocks_x) * 8u;
+        w.block_x0 = (tile % (uint32_t)rp.tiles_x) * (uint32_t)rp.tile_w + bx;
+        w.block_y0 = (tile / (uint32_t)rp.tiles_x) * (uint32_t)rp.tile_h + by;
+        w.block_packed0 = (local_tile * (uint32_t)rp.tile_h + by) * (uint32_t)rp.tile_w + bx;
+        if (rp.wave_log && lane == 0) {
+            rp.wave_log[4 * gw + 2] = wall_clock64();
+            rp.wave_log[4 * gw + 3] = (unsigned long long)w.block_x0 | ((unsigned long long)w.block_y0 << 16) | ((unsigned long long)run.queue << 32);
+        }
+        return;
+    }
+}
+
+// The rounds of a wave in a staged launch: render_kernel's scheduler over the same traversal steps.  `mailbox`: 64 words
+// of LDS of this wave's own.
+template <bool PRUNE, bool STATS>
+__device__ __forceinline__ void stage_loop(Lane &L, Wave &w, const DevScene &sc, const DevRender &rp, const Hot &hot, uint32_t *stack,
+                                           uint32_t stride, const Scratch &scr, Counters &c, uint32_t *mailbox, uint32_t lane, uint64_t gw) {
+    Run run = {0u, 0u, 0u, 0u, 0ull};
+    for (;;) {
+        const unsigned long long m_inner = __ballot(L.state == ST_INNER);
+        const unsigned long long m_leaf = __ballot(L.state == ST_LEAF);
+        const unsigned long long m_shade = __ballot(L.state == ST_SHADE);
+        unsigned long long m_fetch = __ballot(L.state == ST_FETCH);
+        if (m_fetch != 0ull && w.drained && run.mask == 0ull) {         // the queues are empty: lanes without work are done
+            if (L.state == ST_FETCH) L.state = ST_DONE;
+            m_fetch = 0ull;
+        }
+        if ((m_inner | m_leaf | m_shade | m_fetch) == 0) return;        // every lane done
+        // Starting an item costs the whole wave two trips to memory (the pixel's records, then its triangle), so lanes
+        // without work are served in batches: when rp.refill_min of them wait, or when nothing else is left to do
+        const bool refill = (int)__popcll(m_fetch) >= rp.refill_min || (m_inner | m_leaf | m_shade) == 0ull;
+        const int n_inner = __popcll(m_inner), n_leaf = __popcll(m_leaf), n_shade = __popcll(m_shade | (refill ? m_fetch : 0ull));
+        const int w_inner = n_inner * hot.w_inner, w_leaf = n_leaf * hot.w_leaf, w_shade = n_shade * hot.w_shade;
+        const bool all_kinds = n_inner + n_leaf + n_shade <= hot.tail_lanes;
+        const bool pick_inner = w_inner >= w_leaf && w_inner >= w_shade;
+        const bool pick_leaf = !pick_inner && w_leaf >= w_shade;
+        if (pick_inner || (all_kinds && n_inner) || n_inner >= hot.also_lanes) {
+            if (STATS && lane == 0) { w.rounds[0]++; w.lane_steps[0] += n_inner; }
+            if (L.state == ST_INNER) inner_step<PRUNE, STATS>(L, hot, stack, stride, c);
+        }
+        if (pick_leaf || (all_kinds && n_leaf) || n_leaf >= hot.also_leaf) {
+            if (STATS) { const int k = __popcll(__ballot(L.state == ST_LEAF)); if (lane == 0) { w.rounds[1]++; w.lane_steps[1] += k; } }
+            if (L.state == ST_LEAF) leaf_step<PRUNE, STATS>(L, hot, stack, stride, c);
+        }
+        if ((!pick_inner && !pick_leaf) || (all_kinds && n_shade) || n_shade >= hot.also_shade) {
+            if (STATS) { const int k = __popcll(__ballot(L.state == ST_SHADE)); if (lane == 0) { w.rounds[2]++; w.lane_steps[2] += k; } }
+            if (L.state == ST_SHADE) stage_finish<PRUNE, STATS>(L, sc, rp, scr, c, hot.root_ref);
+            // hand the waiting pixels of the wave's block to the lanes without work: the k-th such lane takes the k-th pixel
+            unsigned long long need = refill ? __ballot(L.state == ST_FETCH) : 0ull;
+            while (need) {
+                if (run.mask == 0ull && !w.drained) draw_staged(w, run, rp, lane, gw);
+                if (run.mask == 0ull) {                                 // nothing left anywhere
+                    if (L.state == ST_FETCH) L.state = ST_DONE;
+                    break;
+                }
+                // lane j speaks for pixel j of the block: if that pixel waits and is among the first n_need waiting
+                // ones, it leaves its number in the mailbox slot of its rank, where the lane of that rank finds it
+                const uint32_t n_need = (uint32_t)__popcll(need);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const bool waits = (run.mask >> lane) & 1ull;
+                const uint32_t my_rank = (uint32_t)__popcll(run.mask & below);
+                const bool taken = waits && my_rank < n_need;
+                if (taken) mailbox[my_rank] = lane;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave's LDS accesses stay in this order
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const unsigned long long m_taken = __ballot(taken);
+                const uint32_t rank = (uint32_t)__popcll(need & below);
+                if (L.state == ST_FETCH && rank < (uint32_t)__popcll(m_taken)) {
+                    const uint32_t in = mailbox[rank], ix = in & 7u, iy = in >> 3;
+                    const uint32_t col = w.block_x0 + ix, row = w.block_y0 + iy;
+                    // outside the frame or the window: nothing to render, the lane asks again
+                    if ((int)col >= rp.x0 && (int)col < rp.x1 && (int)row >= rp.y0 && (int)row < rp.y1) {
+                        L.pix = col | (row << 16);
+                        L.out = (rp.layout == RTX_LAYOUT_PACKED_TILES_) ? w.block_packed0 + iy * (uint32_t)rp.tile_w + ix : row * (uint32_t)rp.W + col;
+                        L.blk = run.blk;
+                        stage_begin<PRUNE, STATS>(L, sc, rp, scr, hot.root_ref, rp.pass_kind[w.frame]);
+                    }
+                }
+                run.mask &= ~m_taken;
+                // the blend was the last reader of the block's masks: they go back to zero for the slot's next frame
+                if (run.mask == 0ull && rp.pass_kind[w.frame] == SP_RESOLVE && lane <= (uint32_t)rp.depth)
+                    rp.hitmask[(uint64_t)lane * rp.total_blocks + run.blk] = 0ull;
+                need = __ballot(L.state == ST_FETCH);
+            }
+        }
+    }
+}
+
+template <bool PRUNE, bool STATS, bool STAGED>
 __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const DevScene sc_arg, const DevRender rp_arg) {
     // The two argument blocks hold ~100 dwords.  Read as ordinary kernel arguments they are all
     // loaded into scalar registers up front and most of them spilled again; read through the
@@ -1011,7 +1323,7 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
     PixelSum acc = {0, 0, 0};
     L.state = ST_FETCH;
     L.best_t = RTX_INF; L.best_pos = -1; L.first = 0; L.count = 0; L.sp = 0; L.slack = 0; L.lim = {0, 0, 0};
-    L.o = {0, 0, 0}; L.r = {0, 0, 1}; L.path = 0; L.pix = 0; L.out = 0;
+    L.o = {0, 0, 0}; L.r = {0, 0, 1}; L.path = 0; L.pix = 0; L.out = 0; L.blk = 0;
     L.rd = RayDiv{0, 0, 0, 0};
 
     // The launch is persistent: it has only as many waves as the chip holds, and a wave keeps
@@ -1036,7 +1348,9 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
     // queries.  One sample per pixel only (a job's marks live in the sample bits of `path`), and only in scenes with
     // lights.  The steady state runs the first copy, which knows nothing of all this.
     const bool jobs_possible = rp.spp == 1 && (sc.n_point + sc.n_dir) != 0u && rp.lighting_jobs != 0;
-    if (wave_loop<PRUNE, STATS, false>(L, acc, w, sc, rp, hot, stack, stride, scr, c, pend, lane, gw, jobs_possible)) {
+    if (STAGED) {
+        stage_loop<PRUNE, STATS>(L, w, sc, rp, hot, stack, stride, scr, c, pend, lane, gw);
+    } else if (wave_loop<PRUNE, STATS, false>(L, acc, w, sc, rp, hot, stack, stride, scr, c, pend, lane, gw, jobs_possible)) {
         // lanes only run out of work when every queue is empty: from here on no lane takes a new pixel, and the
         // pixels in progress count one party each, their owner's chain
         pend[lane] = (L.state == ST_DONE) ? 0u : 1u;
@@ -1264,14 +1578,19 @@ hipError_t launch_tile_order(uint32_t *d_order, const DevRender &rp, int macro, 
 int render_blocks_per_cu() { return RTX_WAVES_PER_EU; }
 
 hipError_t launch_render(const DevScene &sc, const DevRender &rp, bool prune, bool stats, uint32_t block_threads,
-                         uint32_t grid_blocks, hipStream_t st) {
+                         uint32_t grid_blocks, hipStream_t st, bool staged) {
     if (rp.total_blocks == 0 || grid_blocks == 0) return hipSuccess;
     dim3 grid(grid_blocks), block(block_threads);
     const size_t lds = render_lds_bytes(sc.bvh_depth, block_threads) + (size_t)sc.n_top_pairs * 128;
-    if (prune && stats) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, lds, st, sc, rp);
-    else if (prune) hipLaunchKernelGGL((render_kernel<true, false>), grid, block, lds, st, sc, rp);
-    else if (stats) hipLaunchKernelGGL((render_kernel<false, true>), grid, block, lds, st, sc, rp);
-    else hipLaunchKernelGGL((render_kernel<false, false>), grid, block, lds, st, sc, rp);
+    if (staged) {
+        if (prune && stats) hipLaunchKernelGGL((render_kernel<true, true, true>), grid, block, lds, st, sc, rp);
+        else if (prune) hipLaunchKernelGGL((render_kernel<true, false, true>), grid, block, lds, st, sc, rp);
+        else if (stats) hipLaunchKernelGGL((render_kernel<false, true, true>), grid, block, lds, st, sc, rp);
+        else hipLaunchKernelGGL((render_kernel<false, false, true>), grid, block, lds, st, sc, rp);
+    } else if (prune && stats) hipLaunchKernelGGL((render_kernel<true, true, false>), grid, block, lds, st, sc, rp);
+    else if (prune) hipLaunchKernelGGL((render_kernel<true, false, false>), grid, block, lds, st, sc, rp);
+    else if (stats) hipLaunchKernelGGL((render_kernel<false, true, false>), grid, block, lds, st, sc, rp);
+    else hipLaunchKernelGGL((render_kernel<false, false, false>), grid, block, lds, st, sc, rp);
     return hipGetLastError();
 }
 
