@@ -258,7 +258,11 @@ def main():
 
         cen_ref, _ = census(rt.TRAVERSAL_REFERENCE)     # canonical (reference traversal) work, whole frame
         cen_own, sched_own = census(mode)               # what the timed kernel itself visits, and how full its rounds are
+        # The frame's rays as the reference traces them (the unit of `value` and of the CPU baseline).  The pruned walk does not
+        # ask a shadow query whose light cannot add anything to the surface (it faces away and no specular term applies:
+        # scene.hpp:165-180), so it traces fewer rays for the same pixels; that count is reported beside it.
         rays = cen_ref["primary_rays"] + cen_ref["reflection_rays"] + cen_ref["shadow_rays"]
+        rays_traced = cen_own["primary_rays"] + cen_own["reflection_rays"] + cen_own["shadow_rays"]
 
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         # device-side start (as its complement) and end of every timed launch (100 MHz ticks), left by the kernel itself in
@@ -300,7 +304,7 @@ def main():
         alone_ms = (time.perf_counter() - t1) * 1e3 / n1
 
         m = dict(family=family, host=host, scene=scene, renderer=renderer, obj_path=obj_path, obj_dir=obj_dir, load_s=load_s,
-                 create_s=create_s, cen_ref=cen_ref, cen_own=cen_own, sched=sched_own, rays=rays, elapsed=elapsed, steps=steps,
+                 create_s=create_s, cen_ref=cen_ref, cen_own=cen_own, sched=sched_own, rays=rays, rays_traced=rays_traced, elapsed=elapsed, steps=steps,
                  ms_per_step=elapsed * 1e3 / steps, event_ms=event_ms, kernel_ms=kernel_ms, crc=frame_crc, alone_ms=alone_ms)
 
         # several frames per launch (rtx_render_device_batch): the overlap of frames in flight without their streams
@@ -430,6 +434,9 @@ def main():
         "metric": "Mrays/s (primary+reflection+shadow)",
         "value": round(mrays, 2),
         "unit": "Mrays/s",
+        # `value` counts the frame's rays as the reference traces them (what the CPU baseline is measured in); the timed
+        # kernel skips shadow queries that cannot change the pixel, so it traces fewer: the same frames per second in its own rays
+        "value_in_rays_the_timed_kernel_traced": round(head["rays_traced"] / (ms_per_step * 1e-3) / 1e6, 2),
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
@@ -447,6 +454,7 @@ def main():
                            + ((", RCCL all-gather of packed tiles" if args.backend == "nccl" else ", gloo all-gather through host memory (rehearsal)") if packed else ""),
             "rays_per_frame": rays,
             "rays_per_pixel": round(rays / (W * H), 3),
+            "rays_traced_per_frame_by_the_timed_kernel": head["rays_traced"],
             "bvh_nodes": scene.bvh_nodes,
             "bvh_depth": scene.bvh_depth,
             "scene_hbm_bytes": scene.device_bytes,
@@ -480,6 +488,7 @@ def main():
             "frame_ms_latency": round(other["alone_ms"], 4),
             "ms_per_frame_four_frames_per_launch": None if "batch_ms_per_frame" not in other else round(other["batch_ms_per_frame"], 4),
             "rays_per_frame": other["rays"],
+            "rays_traced_per_frame_by_the_timed_kernel": other["rays_traced"],
             "rays_per_pixel": round(other["rays"] / (W * H), 3),
             "frame_crc32": other["crc"],
             "roofline": {k: o_roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "lane_utilisation", "frac_useful_lanes",

@@ -131,6 +131,7 @@ struct Light { double intensity; V3 v; };
 
 struct Counters {
     uint64_t primary = 0, reflection = 0, shadow = 0, occluded = 0, closest_hits = 0;
+    uint64_t shadow_idle = 0, shadow_idle_occluded = 0;   // shadow queries whose answer cannot change the light's term (it is 0 either way)
     uint64_t nodes = 0, box_hits = 0, leaves = 0, tris = 0;
 };
 
@@ -326,6 +327,10 @@ double light_term(const ora_scene &s, double intensity, V3 L, double tmax, V3 p,
     double total = 0.0;
     c.shadow++;
     Hit sh = query(s, p, L, 0.001, tmax, use_bvh, c);
+    // census only: would the light add anything if it were visible?  (the GPU path's pruned walk does not ask the
+    // query when it would not; the test of that count reads these two)
+    const bool idle = !(dot(n, L) > 0.0) && (spec == -1 || !(dot(reflect_ray(L, n), v) > 0));
+    if (idle) { c.shadow_idle++; if (sh.any) c.shadow_idle_occluded++; }
     if (sh.any) { c.occluded++; return total; }
     double nl = dot(n, L);
     if (nl > 0.0) {
@@ -624,6 +629,7 @@ int ora_render(ora_scene *s, int32_t W, int32_t H, int32_t depth, int32_t spp, u
             census->shadow_rays += c.shadow; census->shadow_occluded += c.occluded;
             census->closest_hits += c.closest_hits; census->node_visits += c.nodes;
             census->box_hits += c.box_hits; census->leaf_visits += c.leaves; census->triangle_tests += c.tris;
+            census->shadow_idle += c.shadow_idle; census->shadow_idle_occluded += c.shadow_idle_occluded;
         }
     }
     return 0;

@@ -35,6 +35,10 @@ typedef struct ora_census {
     uint64_t box_hits;         /* slab tests that passed                       */
     uint64_t leaf_visits;
     uint64_t triangle_tests;   /* Triangle::intersectRay calls                 */
+    /* shadow queries whose light adds 0 to the surface whether it is visible or not (N.L <= 0 and no specular
+     * term, scene.hpp:165-180), and those of them that found an occluder: what a renderer may leave untraced */
+    uint64_t shadow_idle;
+    uint64_t shadow_idle_occluded;
 } ora_census;
 
 /* Scene from raw arrays; the Triangle ctor work (normal, centroid) and the BVH

@@ -293,6 +293,16 @@ __device__ __forceinline__ V3 reflect_ray(V3 ray, V3 n) {              // scene.
     return sub(muls(smul(2.0, n), dot(n, ray)), ray);
 }
 
+// Scene::computeLighting (scene.hpp:147-183) asks its shadow query first and only then looks at the surface: the diffuse
+// term needs N.L > 0 (:165-170), the specular term specularity != -1 and R.V > 0 (:172-180).  Where both conditions fail
+// the light adds 0 whatever the query answers, so the query need not be asked (the pruned walk only; the reference walk
+// traces what the reference traces).  The same expressions as the terms themselves: the same values, the same decisions.
+__device__ __forceinline__ bool light_adds_nothing(V3 n, V3 v, int spec, V3 light) {
+    if (dot(n, light) > 0.0) return false;
+    if (spec == -1) return true;
+    return !(dot(reflect_ray(light, n), v) > 0);
+}
+
 // Distance pruning (PRUNE) skips a box when, on SOME axis, the ray enters the box's slab
 // later than limit + slack, where limit is the best accepted t so far (or tmax).
 // Why a slack: a triangle's t comes from the plane equation (triangle.hpp:40), a slab
@@ -631,6 +641,8 @@ __device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScen
     int cr = sc.bg[0], cg = sc.bg[1], cb = sc.bg[2];
     bool lights = false;       // a shadow query was answered, or the first one is due
     bool elsewhere = false;    // TAIL: the lighting of this hit is a job's business
+    V3 sn = {0, 0, 0}, sv = {0, 0, 0};   // PRUNE: the surface's normal, -ray and specularity, for light_adds_nothing()
+    int sspec = -1;
     if (kind == 0) {
         // Scene::traceRay after the closest-hit query (scene.hpp:97-111)
         if (STATS && !job) c.v[d == 0 ? C_PRIMARY : C_REFLECTION]++;
@@ -651,6 +663,7 @@ __device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScen
             li = 0;
             elsewhere = TAIL && handed_over;
             lights = !elsewhere;
+            if (PRUNE && lights && n_lights != 0u) { sn = ld3(sc.tris[L.best_pos].n); sv = v; sspec = sc.mats[L.best_pos].specularity; }
         }
     } else {
         // the rest of Scene::computeLighting (scene.hpp:159-182) with light = r, point = o
@@ -678,16 +691,22 @@ __device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScen
         }
         li++;
         lights = true;
+        if (PRUNE && li < n_lights) {
+            const int32_t pos = scr.i(0);
+            sn = ld3(sc.tris[pos].n); sv = {scr.f(0), scr.f(1), scr.f(2)}; sspec = sc.mats[pos].specularity;
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
     Scratch px = scr;          // TAIL: the scratch of the pixel this step finishes, the lane's own or a job's owner's
     bool finish = false;       // TAIL: this lane is the last party of that pixel
     if (lights) {
-        if (li < n_lights) {
+        for (; li < n_lights; li++) {
             // computeTotalLighting (scene.hpp:130-142): point lights first (light = position -
             // point, tMax = 1), then directional ones (light = direction, tMax = inf)
             const V3 lv = ld3(sc.lights[li].v);
-            L.r = (li < sc.n_point) ? sub(lv, L.o) : lv;
+            const V3 light = (li < sc.n_point) ? sub(lv, L.o) : lv;
+            if (PRUNE && light_adds_nothing(sn, sv, sspec, light)) continue;
+            L.r = light;
             L.path = (L.path & 0xFFFEu) | 1u | (li << 16);              // a shadow query of light li; depth and sample (or job marks) stay
             start_query(L, sc, PRUNE, root_ref);
             return;
@@ -1008,6 +1027,29 @@ __device__ __forceinline__ void put_pixel(const DevRender &rp, uint64_t out, int
     if (rp.rgb_i32) { rp.rgb_i32[3 * out + 0] = cr; rp.rgb_i32[3 * out + 1] = cg; rp.rgb_i32[3 * out + 2] = cb; }
 }
 
+// Starts the shadow query of the first light from `li` on that can add anything to the surface whose -ray, lighting sum and
+// triangle lie in the lane's scratch (computeTotalLighting, scene.hpp:130-142: point lights first, then directional ones).
+// False: no such light is left.
+template <bool PRUNE>
+__device__ __forceinline__ bool stage_next_light(Lane &L, const DevScene &sc, const Scratch &scr, uint32_t root_ref, uint32_t lv, uint32_t li) {
+    V3 sn = {0, 0, 0}, sv = {0, 0, 0};
+    int sspec = -1;
+    if (PRUNE) {
+        const int32_t pos = scr.i(0);
+        sn = ld3(sc.tris[pos].n); sv = {scr.f(0), scr.f(1), scr.f(2)}; sspec = sc.mats[pos].specularity;
+    }
+    for (; li < sc.n_point + sc.n_dir; li++) {
+        const V3 lvec = ld3(sc.lights[li].v);
+        const V3 light = (li < sc.n_point) ? sub(lvec, L.o) : lvec;
+        if (PRUNE && light_adds_nothing(sn, sv, sspec, light)) continue;
+        L.r = light;
+        L.path = make_path(1, lv, 0, li);
+        start_query(L, sc, PRUNE, root_ref);
+        return true;
+    }
+    return false;
+}
+
 // A finished query of a staged launch.  Leaves the lane with the next shadow query of the same hit or without work.
 template <bool PRUNE, bool STATS>
 __device__ __forceinline__ void stage_finish(Lane &L, const DevScene &sc, const DevRender &rp, const Scratch &scr, Counters &c,
@@ -1062,14 +1104,7 @@ __device__ __forceinline__ void stage_finish(Lane &L, const DevScene &sc, const 
         scr.f(3) += term;
     }
     li++;
-    if (li < sc.n_point + sc.n_dir) {
-        // computeTotalLighting (scene.hpp:130-142): point lights first, then directional ones
-        const V3 lvec = ld3(sc.lights[li].v);
-        L.r = (li < sc.n_point) ? sub(lvec, L.o) : lvec;
-        L.path = make_path(1, lv, 0, li);
-        start_query(L, sc, PRUNE, root_ref);
-        return;
-    }
+    if (li < sc.n_point + sc.n_dir && stage_next_light<PRUNE>(L, sc, scr, root_ref, lv, li)) return;
     stage_level_done(sc, rp, scr, lv, out);
     L.state = ST_FETCH;
 }
@@ -1107,14 +1142,7 @@ __device__ __forceinline__ void stage_begin(Lane &L, const DevScene &sc, const D
         scr.f(0) = v.x; scr.f(1) = v.y; scr.f(2) = v.z;
         scr.f(3) = sc.ambient;                                          // scene.hpp:128
         scr.i(0) = pos;
-        if (sc.n_point + sc.n_dir == 0u) {
-            stage_level_done(sc, rp, scr, from, out);
-            return;
-        }
-        const V3 lvec = ld3(sc.lights[0].v);
-        L.r = (sc.n_point != 0u) ? sub(lvec, L.o) : lvec;
-        L.path = make_path(1, from, 0, 0);
-        start_query(L, sc, PRUNE, root_ref);
+        if (!stage_next_light<PRUNE>(L, sc, scr, root_ref, from, 0u)) stage_level_done(sc, rp, scr, from, out);
         return;
     }
     // SP_RESOLVE (pixels whose camera ray hit): walk the pixel's levels down to where its chain ended, then blend back

@@ -17,14 +17,14 @@ LIB = os.path.join(ORACLE_DIR, "liboracle.so")
 class Census(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "primary_rays", "reflection_rays", "shadow_rays", "shadow_occluded", "closest_hits",
-        "node_visits", "box_hits", "leaf_visits", "triangle_tests")]
+        "node_visits", "box_hits", "leaf_visits", "triangle_tests", "shadow_idle", "shadow_idle_occluded")]
 
     @property
     def rays(self):
         return self.primary_rays + self.reflection_rays + self.shadow_rays
 
     def as_dict(self):
-        d = {n: getattr(self, n) for n, _ in self._fields_}
+        d = {n: getattr(self, n) for n, _ in self._fields_ if not n.startswith("shadow_idle")}
         d["rays"] = self.rays
         return d
 

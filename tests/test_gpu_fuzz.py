@@ -53,7 +53,7 @@ def test_random_case_is_bit_exact(seed):
         if o["mode"] == rt.TRAVERSAL_REFERENCE:
             got = [int(x) for x in stats.cpu().numpy()[:9]]
             cen = want["census"]
-            assert got == [getattr(cen, name) for name, _ in cen._fields_], tag
+            assert got == [getattr(cen, name) for name, _ in cen._fields_[:9]], tag
     finally:
         dev.close()
         ora.close()

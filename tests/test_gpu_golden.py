@@ -124,8 +124,12 @@ def test_full_size_modes_agree_and_census_is_canonical():
     b = dev.render(W, H, traversal=rt.TRAVERSAL_PRUNED, want_stats=True)
     assert np.array_equal(a.hit, b.hit) and np.array_equal(a.rgb, b.rgb)
     sa, sb = a.stats.as_dict(), b.stats.as_dict()
-    for k in ("primary_rays", "reflection_rays", "shadow_rays", "shadow_occluded", "closest_hits"):
+    for k in ("primary_rays", "reflection_rays", "closest_hits"):
         assert sa[k] == sb[k]
+    # the pruned walk leaves out shadow queries of lights that cannot add anything to the surface
+    # (tests/test_gpu_parity.py pins how many against the oracle)
+    assert sb["shadow_rays"] <= sa["shadow_rays"] and sb["shadow_occluded"] <= sa["shadow_occluded"]
+    assert sa["shadow_rays"] - sb["shadow_rays"] >= sa["shadow_occluded"] - sb["shadow_occluded"]
     assert sa["primary_rays"] == W * H
     assert sb["node_visits"] <= sa["node_visits"] and sb["triangle_tests"] <= sa["triangle_tests"]
     from scenes_util import untile_reference

@@ -40,6 +40,22 @@ def test_teapot_census_matches_reference_traversal(teapot):
     assert got == want
 
 
+def test_pruned_walk_skips_exactly_the_shadow_queries_that_cannot_matter(teapot):
+    """Scene::computeLighting asks its shadow query before it looks at the surface (scene.hpp:155-180).  The pruned walk does
+    not ask when the light adds 0 either way (N.L <= 0 and no specular term); the oracle counts those queries, and the
+    pruned walk's counters must be the reference walk's minus exactly them."""
+    _, dev, ora = teapot
+    census = ora.render(200, 200, depth=3)["census"]
+    ref = dev.render(200, 200, depth=3, traversal=rt.TRAVERSAL_REFERENCE, want_stats=True).stats.as_dict()
+    got = dev.render(200, 200, depth=3, traversal=rt.TRAVERSAL_PRUNED, want_stats=True).stats.as_dict()
+    assert census.shadow_idle > 0
+    assert ref["shadow_rays"] == census.shadow_rays
+    assert got["shadow_rays"] == census.shadow_rays - census.shadow_idle
+    assert got["shadow_occluded"] == census.shadow_occluded - census.shadow_idle_occluded
+    for k in ("primary_rays", "reflection_rays", "closest_hits"):
+        assert got[k] == ref[k]
+
+
 @pytest.mark.parametrize("depth", [0, 1, 2, 5])
 def test_teapot_depths(teapot, depth):
     _, dev, ora = teapot
