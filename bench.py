@@ -122,7 +122,7 @@ def main():
                     help="stand-in mesh family of the headline: knot = a knotted tube (concave, self-occluding, self-reflecting) in a "
                          "box that fills the view: 6.4 rays per pixel, the ray statistics of the reference's one real scene "
                          "(teapot: 6.1); blob = a bumpy star-shaped surface in a box around z = 0: 2.8 rays per pixel, most "
-                         "reflected rays leave the scene (the headline of rounds 1 and 2).  The other family is measured in the "
+                         "reflected rays leave the scene.  The other family is measured in the "
                          "same run and reported as `other_family`")
     ap.add_argument("--no-other-family", action="store_true", help="skip the second stand-in family")
     ap.add_argument("--obj", default=None, help="real .obj for the scene (default: the seeded stand-in mesh)")
