@@ -385,6 +385,9 @@ struct Lane {
     uint32_t pix;        // the pixel: column | row << 16
     uint32_t out;        // its index in the output buffers (row-major or packed-tile layout)
     uint32_t blk;        // staged launches: the pixel's 8x8 block (index into DevRender::hitmask)
+#ifdef RTX_EXPERIMENT_STEPHIST
+    uint32_t steps;      // MEASUREMENT ONLY (tools/step_histogram.py): node-pair steps of the running query
+#endif
 };
 
 __device__ __forceinline__ uint32_t path_kind(uint32_t p) { return p & 1u; }
@@ -451,6 +454,9 @@ __device__ __forceinline__ void start_query(Lane &L, const DevScene &sc, bool pr
     L.count = 0;
     L.sp = 0;
     L.state = ST_INNER;
+#ifdef RTX_EXPERIMENT_STEPHIST
+    L.steps = 0;
+#endif
 }
 
 // A stack entry says where to continue without another trip to memory:
@@ -520,6 +526,9 @@ __device__ __forceinline__ void inner_step(Lane &L, const Hot &hot, uint32_t *st
         ha = slab(a_lo, a_hi, L.o, L.r, L.lim, &ta, &beyond_a);
         hb = slab(b_lo, b_hi, L.o, L.r, L.lim, &tb, &beyond_b);
     }
+#ifdef RTX_EXPERIMENT_STEPHIST
+    L.steps++;
+#endif
     if (STATS) {
         c.v[C_NODES] += root_pair ? 1 : 2;    // slot 0 is not a node of the tree
         c.v[C_BOXHITS] += (ha ? 1 : 0) + (hb ? 1 : 0);
@@ -636,6 +645,16 @@ __device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScen
     const uint32_t n_lights = sc.n_point + sc.n_dir;
     const uint32_t kind = path_kind(L.path), s = path_s(L.path);
     const bool job = TAIL && (L.path & kJob) != 0;
+#ifdef RTX_EXPERIMENT_STEPHIST
+    // MEASUREMENT ONLY: the caller's counter array continues with [16 + 12 kind + b] queries and [40 + 12 kind + b] their
+    // node-pair steps, b = bucket (0: under 8 steps, 1: 8..15, 2: 16..31, ... 8: 1024 and up), kind 0 = closest hit, 1 = shadow
+    if (STATS && rp.stats && !(job && kind == 0)) {
+        uint32_t b = L.steps < 8u ? 0u : 29u - (uint32_t)__builtin_clz(L.steps);
+        b = b > 8u ? 8u : b;
+        atomicAdd(&rp.stats[16u + 12u * kind + b], 1ull);
+        atomicAdd(&rp.stats[40u + 12u * kind + b], (unsigned long long)L.steps);
+    }
+#endif
     uint32_t d = path_d(L.path), li = path_li(L.path);
     bool path_done = false;    // the chain has ended: (cr, cg, cb) is its innermost colour
     int cr = sc.bg[0], cg = sc.bg[1], cb = sc.bg[2];
