@@ -295,7 +295,7 @@ int rtx_render_device_timed(rtx_scene *scene, const rtx_render_params *p, void *
  * closest-hit queries of every pixel that still has one, together with the shadow queries of the level l-1 hits
  * (a hit's lighting and its reflection only meet in the blend, scene.hpp:113,119-122), lanes are refilled query by
  * query, and a last launch blends each pixel's levels and writes it.  Same pixels, ids, t and counters, bit for bit.
- * Costs 48 + 24 (depth + 1) bytes of HBM per output pixel (kept with the scene handle per frame in flight).
+ * Costs 96 + 24 (depth + 1) bytes of HBM per output pixel (kept with the scene handle per frame in flight).
  * One sample per pixel only (RTX_ERR_UNSUPPORTED otherwise).  Arguments as rtx_render_device_timed(). */
 int rtx_render_device_staged(rtx_scene *scene, const rtx_render_params *p, void *d_rgb_u8, void *d_hit_id,
                              void *d_rgb_i32, void *d_t, void *d_stats, void *d_ticks, void *stream);
