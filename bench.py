@@ -42,6 +42,8 @@ def profiled_counters(workload_key, kernel_build):
          "valu_instructions": t.get("SQ_INSTS_VALU"), "kernel_build": t["kernel_build"]}
     if t.get("SQ_THREAD_CYCLES_VALU") and t.get("SQ_ACTIVE_INST_VALU"):
         c["lanes_per_valu_instruction"] = t["SQ_THREAD_CYCLES_VALU"] / t["SQ_ACTIVE_INST_VALU"]
+    c["l1_accesses"] = t.get("TCP_TOTAL_CACHE_ACCESSES_sum")
+    c["l2_requests"], c["l2_hits"] = t.get("TCC_REQ_sum"), t.get("TCC_HIT_sum")
     return c, None
 
 
@@ -391,6 +393,12 @@ def main():
             "hbm": None if not counters else {
                 "achieved": round(counters["bytes"] / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(counters["bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            # vector L1 (one per CU): tag accesses of a launch (counter pass) per clock and CU over the time per frame; every
+            # 16-byte load of a lane that does not share its line with a neighbour is one access, and the kernel lives on such loads
+            "l1": None if not (counters and counters.get("l1_accesses")) else {
+                "accesses_per_launch": int(counters["l1_accesses"]),
+                "per_clock_per_cu": round(counters["l1_accesses"] / (ms * 1e-3 * CLOCK_GHZ * 1e9) / max(1, simds // 4), 4),
+                "l2_hit_rate": None if not counters.get("l2_requests") else round(counters["l2_hits"] / counters["l2_requests"], 4)},
             # cache side: the bytes the timed kernel asks for (its own census: 128 B per node pair, 112 B per triangle;
             # the top of the tree is served from LDS, the rest by L1 / L2 / Infinity Cache) against the L2s' aggregate peak
             "l2": {"own_bytes_per_launch": int(own_bytes / world), "achieved": round(own_bytes / world / (ms * 1e-3) / 1e9, 1),

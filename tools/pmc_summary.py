@@ -26,7 +26,7 @@ if len(sys.argv) >= 5 and "FETCH_SIZE" in out and "WRITE_SIZE" in out:
     table = json.load(open(path)) if os.path.exists(path) else {}
     table[key] = {"FETCH_SIZE_KiB": out["FETCH_SIZE"]["mean_per_dispatch"], "WRITE_SIZE_KiB": out["WRITE_SIZE"]["mean_per_dispatch"],
                   "source": os.path.basename(sys.argv[2])}
-    for name in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU"):
+    for name in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCC_REQ_sum", "TCC_HIT_sum"):
         if name in out:
             table[key][name] = out[name]["mean_per_dispatch"]
     # which kernels the counters were taken from: the hash of the kernel sources this tree's library was built from
