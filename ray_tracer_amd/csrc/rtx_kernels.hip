@@ -58,12 +58,12 @@ __device__ __forceinline__ double lane_value(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
-// A node pair or a triangle is fetched with 16-byte loads issued back to back and kept
-// in registers; pin() stops the compiler from sinking some of those loads below the
-// first arithmetic (it would, to save registers, and a step would then pay two or three
-// memory round trips instead of one).
+// A node pair or a triangle is fetched with 16-byte loads issued back to back and kept in registers.  issued() keeps
+// the compiler from sinking some of those loads below the first arithmetic (it would, to save registers, and a step would
+// then pay two or three memory round trips instead of one): nothing is scheduled across it.  It does not wait: the
+// arithmetic on the first pieces starts while the last ones are still on their way (each wait sits at a piece's first use).
 typedef double d2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void pin(d2 &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void issued() { __builtin_amdgcn_sched_barrier(0); }
 
 // ---- exact division by a per-ray constant --------------------------------------
 // The slab test divides twelve box distances per node pair by the same three ray
@@ -507,7 +507,7 @@ __device__ __forceinline__ void inner_step(Lane &L, const Hot &hot, uint32_t *st
         // sibling's box -- seven loads; every byte a wave asks its L1 for counts here
         const d2 *line = reinterpret_cast<const d2 *>(nodes + L.first);
         q0 = line[0]; q1 = line[1]; q2 = line[2]; q3 = line[3]; q4 = line[4]; q5 = line[5]; q6 = line[6];
-        pin(q0); pin(q1); pin(q2); pin(q3); pin(q4); pin(q5); pin(q6);
+        issued();
     }
     const bool root_pair = (L.first & ~kTopFlag) == 0;                   // slots (0, 1)
     const double a_lo[3] = {q0.x, q0.y, q1.x}, a_hi[3] = {q1.y, q2.x, q2.y};
@@ -562,7 +562,7 @@ __device__ __forceinline__ void leaf_step(Lane &L, const Hot &hot, const uint32_
     // 112 of the record's 128 bytes: seven 16-byte loads, one round trip
     const d2 *rec = reinterpret_cast<const d2 *>(hot.tris + L.first);
     d2 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6];
-    pin(q0); pin(q1); pin(q2); pin(q3); pin(q4); pin(q5); pin(q6);
+    issued();
     const V3 v0 = {q0.x, q0.y, q1.x}, v1 = {q1.y, q2.x, q2.y}, v2 = {q3.x, q3.y, q4.x}, n = {q4.y, q5.x, q5.y};
     const double plane_d = q6.x;
     const uint32_t leaf_first = (uint32_t)__double2hiint(q6.y);          // {orig_id, leaf_first}
