@@ -37,10 +37,12 @@ constexpr uint32_t kTopFlag = 0x40000000u;
 // pairs the table may hold at most (its queue lives in the build kernel's LDS)
 constexpr uint32_t kTopPairsMax = 512;
 
+// Members in the order the intersection test uses them: the plane (n, d) first, so that the distance along the ray is
+// being computed while the vertices are still on their way.
 struct alignas(128) DevTri {
-    double v0[3], v1[3], v2[3];
     double n[3];       // Triangle::normal, computed on the host (triangle.hpp:21-23)
     double d;          // -(n . v0), the per-call constant of triangle.hpp:39
+    double v0[3], v1[3], v2[3];
     uint32_t orig_id;  // index into the reference's Scene::triangles
     uint32_t leaf_first;
     double pad[2];

@@ -506,7 +506,11 @@ __device__ __forceinline__ void inner_step(Lane &L, const Hot &hot, uint32_t *st
         // 112 of the pair's 128 bytes: the first record whole (its padding repeats the sibling's {first, count}) and the
         // sibling's box -- seven loads; every byte a wave asks its L1 for counts here
         const d2 *line = reinterpret_cast<const d2 *>(nodes + L.first);
-        q0 = line[0]; q1 = line[1]; q2 = line[2]; q3 = line[3]; q4 = line[4]; q5 = line[5]; q6 = line[6];
+        q0 = line[0]; q1 = line[1]; q2 = line[2];
+        issued();
+        q4 = line[4]; q5 = line[5]; q6 = line[6];
+        issued();
+        q3 = line[3];
         issued();
     }
     const bool root_pair = (L.first & ~kTopFlag) == 0;                   // slots (0, 1)
@@ -561,10 +565,15 @@ template <bool PRUNE, bool STATS>
 __device__ __forceinline__ void leaf_step(Lane &L, const Hot &hot, const uint32_t *stack, uint32_t stride, Counters &c) {
     // 112 of the record's 128 bytes: seven 16-byte loads, one round trip
     const d2 *rec = reinterpret_cast<const d2 *>(hot.tris + L.first);
-    d2 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6];
+    // issued in the order of use: the plane, then the vertices
+    const d2 q0 = rec[0], q1 = rec[1];
     issued();
-    const V3 v0 = {q0.x, q0.y, q1.x}, v1 = {q1.y, q2.x, q2.y}, v2 = {q3.x, q3.y, q4.x}, n = {q4.y, q5.x, q5.y};
-    const double plane_d = q6.x;
+    const d2 q2 = rec[2], q3 = rec[3], q4 = rec[4];
+    issued();
+    const d2 q5 = rec[5], q6 = rec[6];
+    issued();
+    const V3 n = {q0.x, q0.y, q1.x}, v0 = {q2.x, q2.y, q3.x}, v1 = {q3.y, q4.x, q4.y}, v2 = {q5.x, q5.y, q6.x};
+    const double plane_d = q1.y;
     const uint32_t leaf_first = (uint32_t)__double2hiint(q6.y);          // {orig_id, leaf_first}
     if (STATS) {
         c.v[C_TRIS]++;
