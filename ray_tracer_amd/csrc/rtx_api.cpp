@@ -937,13 +937,14 @@ static int render_device_timed_impl(rtx_scene *sc, const rtx_render_params *p, v
         sc->slot_key[slot] = key;
     }
     // Diagnostics: RTX_WAVE_LOG=<file> records every wave's start/end tick (100 MHz) of this
-    // launch, when it drew its latest block and which one, as four raw u64 per wave.  Synchronous; never set in production.
+    // launch, when it drew its latest block and which one, as four raw u64 per wave (and two more rows, zero unless the
+    // kernel is a measurement build).  Synchronous; never set in production.
     const char *log_path = getenv("RTX_WAVE_LOG");
     struct DeviceBuffer { void *p = nullptr; ~DeviceBuffer() { (void)hipFree(p); } } log;
     const uint64_t n_waves = plan.grid_blocks * (plan.block / 64);
     if (log_path && *log_path) {
-        HIP_TRY(hipMalloc(&log.p, n_waves * 32));
-        HIP_TRY(hipMemset(log.p, 0, n_waves * 32));
+        HIP_TRY(hipMalloc(&log.p, n_waves * 32 + 64));      // (+ 8 words that only measurement builds of the kernel use)
+        HIP_TRY(hipMemset(log.p, 0, n_waves * 32 + 64));
         r.wave_log = (unsigned long long *)log.p;
     }
     if (staged) {
@@ -970,8 +971,8 @@ static int render_device_timed_impl(rtx_scene *sc, const rtx_render_params *p, v
     }
     HIP_TRY(hipEventRecord(sc->slot_done[slot], st));
     if (log.p) {
-        std::vector<unsigned long long> h(n_waves * 4);
-        HIP_TRY(hipMemcpy(h.data(), log.p, n_waves * 32, hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> h(n_waves * 4 + 8);
+        HIP_TRY(hipMemcpy(h.data(), log.p, n_waves * 32 + 64, hipMemcpyDeviceToHost));
         if (FILE *f = fopen(log_path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }
     return RTX_OK;

@@ -12,10 +12,11 @@ namespace rtx {
 // must equal RTX_LAYOUT_PACKED_TILES in include/rtx.h (checked in rtx_api.cpp)
 constexpr int RTX_LAYOUT_PACKED_TILES_ = 1;
 
-// LDS bytes of a render block's traversal stacks: one u32 slot per tree level per lane, and one more row in
-// which a lane counts the parties still at work on its pixel (see the lighting jobs in render_kernel).
+// LDS bytes of a render block in front of its copy of the top of the tree: the traversal stacks, one u32 slot per tree
+// level per lane; a row in which a lane counts the parties still at work on its pixel (see the lighting jobs in
+// render_kernel); a row that holds the triangle whose lighting the lane is working out; 256 bytes of lights.
 inline size_t render_lds_bytes(int32_t bvh_depth, uint32_t block_threads) {
-    return (size_t)(bvh_depth + 2) * block_threads * sizeof(uint32_t);
+    return (size_t)(bvh_depth + 3) * block_threads * sizeof(uint32_t) + 256;
 }
 // Sibling pairs of the top of the tree a render block keeps in LDS behind its stacks: what is left of
 // the block's share of a CU's 160 KiB (render_blocks_per_cu() blocks of 256 threads, or their

@@ -64,6 +64,14 @@ __device__ __forceinline__ double lane_value(double v, int l) {
 // arithmetic on the first pieces starts while the last ones are still on their way (each wait sits at a piece's first use).
 typedef double d2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void issued() { __builtin_amdgcn_sched_barrier(0); }
+#ifdef RTX_EXPERIMENT_KINDTIME
+// MEASUREMENT ONLY: the shader clock, read where the statement stands (the compiler moves neither memory accesses nor other reads of the clock across it)
+__device__ __forceinline__ unsigned long long cycles_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    return t;
+}
+#endif
 
 // ---- exact division by a per-ray constant --------------------------------------
 // The slab test divides twelve box distances per node pair by the same three ray
@@ -436,6 +444,7 @@ struct Hot {
     const DevNode *nodes;
     const DevTri *tris;
     const d2 *top;       // LDS copy of the top of the tree (DevScene::top), 8 pieces of 16 bytes per pair
+    const double *lights;   // LDS copy of the first lights (see kLdsLights)
     uint32_t root_ref;   // where a walk starts: kTopFlag | 0 with a table, else slot 0
     uint32_t n_point;
     int32_t w_inner, w_leaf, w_shade, tail_lanes, also_lanes, also_leaf, also_shade;
@@ -633,7 +642,20 @@ struct PixelSum {
     int r, g, b;
 };
 
-// A finished query (scene.hpp:89-183).  Leaves the lane with a new query (ST_INNER) or without a pixel (ST_FETCH).
+// A block keeps the scene's first kLdsLights lights in LDS ({intensity, v[3]} each, as in DevLight): the shading step
+// then reads a light without a trip to memory.  Scenes with more lights read all of them from memory.
+constexpr uint32_t kLdsLights = 8;
+__device__ __forceinline__ double light_intensity(const DevScene &sc, const double *lds_lights, uint32_t n_lights, uint32_t li) {
+    return n_lights <= kLdsLights ? lds_lights[4u * li] : sc.lights[li].intensity;
+}
+__device__ __forceinline__ V3 light_vector(const DevScene &sc, const double *lds_lights, uint32_t n_lights, uint32_t li) {
+    if (n_lights <= kLdsLights) return {lds_lights[4u * li + 1u], lds_lights[4u * li + 2u], lds_lights[4u * li + 3u]};
+    return ld3(sc.lights[li].v);
+}
+
+// A finished query (scene.hpp:89-183).  Leaves the lane with a new query (ST_INNER, its origin, direction and `path` set,
+// `new_query` raised: the caller starts all of a round's new queries in one place, start_query() being a good hundred
+// instructions that would otherwise stand in five branches of one round) or without a pixel (ST_FETCH).
 //
 // A pixel is a chain of closest-hit queries (camera ray, then up to `depth` reflections); every surface hit
 // ("level") also needs its lighting: one shadow query per light, in the order of computeTotalLighting.  Levels that
@@ -649,8 +671,30 @@ struct PixelSum {
 // pixel, the owner's chain and its lighting jobs.  A job runs this same code: it starts from a copy of the owner's
 // closest-hit result, walks the lights and delivers the total into the OWNER's scratch.
 template <bool PRUNE, bool STATS, bool TAIL>
-__device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScene &sc, const DevRender &rp, const Scratch &scr,
-                                           Counters &c, uint32_t root_ref, bool handed_over, uint32_t *pend, uint32_t lane) {
+__device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScene &sc, const DevRender &rp, const Scratch &scr_in,
+                                           Counters &c, bool handed_over, uint32_t *pend, uint32_t *surf,
+                                           const double *lds_lights, uint32_t lane_in, bool &new_query,
+                                           unsigned long long *section_cycles = nullptr) {
+    // The lane's number as a value the compiler cannot see through: every address derived from it (the lane's scratch
+    // fields, its LDS slots) is then worked out here, inside the step.  Left visible, they are loop invariants of the
+    // kernel's main loop, get computed once, do not fit the registers and are spilled -- and in this step each reload of
+    // one waits for every load issued before it (s_waitcnt vmcnt(0)), which turns one trip to memory into four.
+    uint32_t lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    Scratch scr = scr_in;
+    scr.id = scr_in.id - lane_in + lane;
+#ifdef RTX_EXPERIMENT_KINDTIME
+    // MEASUREMENT ONLY: section_cycles[k] adds up the cycles between RTX_SECTION(k - 1) and RTX_SECTION(k)
+    unsigned long long section_t = cycles_now();
+    struct SectionEnd {
+        unsigned long long *acc, &t;
+        __device__ ~SectionEnd() { acc[7] += cycles_now() - t; }
+    } section_end{section_cycles, section_t};
+#define RTX_SECTION(k) { const unsigned long long now_ = cycles_now(); section_cycles[k] += now_ - section_t; section_t = now_; }
+#else
+    (void)section_cycles;
+#define RTX_SECTION(k)
+#endif
     const uint32_t n_lights = sc.n_point + sc.n_dir;
     const uint32_t kind = path_kind(L.path), s = path_s(L.path);
     const bool job = TAIL && (L.path & kJob) != 0;
@@ -669,39 +713,57 @@ __device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScen
     int cr = sc.bg[0], cg = sc.bg[1], cb = sc.bg[2];
     bool lights = false;       // a shadow query was answered, or the first one is due
     bool elsewhere = false;    // TAIL: the lighting of this hit is a job's business
-    V3 sn = {0, 0, 0}, sv = {0, 0, 0};   // PRUNE: the surface's normal, -ray and specularity, for light_adds_nothing()
-    int sspec = -1;
+
+    // Everything the step can need of the surface it is about comes in ONE trip to memory, whatever the lane goes on to
+    // do: the triangle's normal and material and, after a shadow query, what the closest-hit step left in the scratch.
+    // (The branches below are taken by different lanes of the wave one after the other; with a trip to memory inside
+    // each of them a shading step took seven times as long as a step of the walk.)  Which triangle the surface is
+    // waits in LDS (*surf) while the shadow queries run; the lights come from LDS too.
+    const int32_t pos = kind == 0 ? L.best_pos : (int32_t)surf[lane];   // -1: the closest-hit query missed
+    V3 n = {0, 0, 1};
+    V3 v = muls(L.r, -1.0);                 // -ray of the query that found the surface (vector3.hpp:108-110)
+    int32_t colour0 = 0, colour1 = 0, colour2 = 0, spec = -1, orig_id = -1;
+    double refl = -1.0, lighting = sc.ambient;                          // scene.hpp:128
+    const bool wants_id = kind == 0 && d == 0 && s == 0 && rp.hit != nullptr;
+    if (pos >= 0) {
+        const d2 *tq = reinterpret_cast<const d2 *>(sc.tris + pos);
+        const d2 n01 = tq[0], n2d = tq[1];
+        const int4 m = *reinterpret_cast<const int4 *>(sc.mats + pos);  // colour, specularity
+        refl = sc.mats[pos].reflectivity;
+        if (wants_id) orig_id = (int32_t)sc.tris[pos].orig_id;
+        if (kind == 1) {
+            v = {scr.f(0), scr.f(1), scr.f(2)};
+            lighting = scr.f(3);
+        }
+        issued();
+        n = {n01.x, n01.y, n2d.x};
+        colour0 = m.x; colour1 = m.y; colour2 = m.z; spec = m.w;
+    }
+    RTX_SECTION(0)          // the trip to memory
     if (kind == 0) {
         // Scene::traceRay after the closest-hit query (scene.hpp:97-111)
         if (STATS && !job) c.v[d == 0 ? C_PRIMARY : C_REFLECTION]++;
         if (d == 0 && s == 0 && (rp.hit || rp.t)) {                     // (a job carries its marks in the sample bits: s != 0)
             const uint64_t k = (uint64_t)(L.pix >> 16) * (uint64_t)rp.W + (uint64_t)(L.pix & 0xFFFFu);
-            if (rp.hit) rp.hit[k] = (L.best_pos >= 0) ? (int32_t)sc.tris[L.best_pos].orig_id : -1;
+            if (rp.hit) rp.hit[k] = orig_id;
             if (rp.t) rp.t[k] = L.best_t;
         }
-        if (L.best_pos < 0) {
+        if (pos < 0) {
             path_done = true;                                           // backgroundColor, scene.hpp:101-103
         } else {
             if (STATS && !job) c.v[C_CLOSEST]++;
             L.o = add(L.o, smul(L.best_t, L.r));                        // point, scene.hpp:105
-            const V3 v = muls(L.r, -1.0);                               // -ray, vector3.hpp:108-110
             scr.f(0) = v.x; scr.f(1) = v.y; scr.f(2) = v.z;
-            scr.f(3) = sc.ambient;                                      // scene.hpp:128
-            scr.i(0) = L.best_pos;
+            surf[lane] = (uint32_t)pos;
             li = 0;
             elsewhere = TAIL && handed_over;
             lights = !elsewhere;
-            if (PRUNE && lights && n_lights != 0u) { sn = ld3(sc.tris[L.best_pos].n); sv = v; sspec = sc.mats[L.best_pos].specularity; }
         }
     } else {
         // the rest of Scene::computeLighting (scene.hpp:159-182) with light = r, point = o
         if (STATS) { c.v[C_SHADOW]++; if (L.best_pos >= 0) c.v[C_OCCLUDED]++; }
         if (L.best_pos < 0) {
-            const int32_t pos = scr.i(0);
-            const V3 n = ld3(sc.tris[pos].n);
-            const V3 v = {scr.f(0), scr.f(1), scr.f(2)};
-            const int spec = sc.mats[pos].specularity;
-            const double intensity = sc.lights[li].intensity;
+            const double intensity = light_intensity(sc, lds_lights, n_lights, li);
             double term = 0.0;
             const double nl = dot(n, L.r);
             if (nl > 0.0) term += intensity * (nl / (mag(n) * mag(L.r)));
@@ -715,36 +777,35 @@ __device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScen
                     term += intensity * ((spec == 1) ? cosv : general_pow(cosv, (double)spec));
                 }
             }
-            scr.f(3) += term;
+            lighting += term;
         }
         li++;
         lights = true;
-        if (PRUNE && li < n_lights) {
-            const int32_t pos = scr.i(0);
-            sn = ld3(sc.tris[pos].n); sv = {scr.f(0), scr.f(1), scr.f(2)}; sspec = sc.mats[pos].specularity;
-        }
     }
     __builtin_amdgcn_sched_barrier(0);
+    RTX_SECTION(1)          // closest-hit bookkeeping / lighting term
     Scratch px = scr;          // TAIL: the scratch of the pixel this step finishes, the lane's own or a job's owner's
     bool finish = false;       // TAIL: this lane is the last party of that pixel
     if (lights) {
         for (; li < n_lights; li++) {
             // computeTotalLighting (scene.hpp:130-142): point lights first (light = position -
             // point, tMax = 1), then directional ones (light = direction, tMax = inf)
-            const V3 lv = ld3(sc.lights[li].v);
+            const V3 lv = light_vector(sc, lds_lights, n_lights, li);
             const V3 light = (li < sc.n_point) ? sub(lv, L.o) : lv;
-            if (PRUNE && light_adds_nothing(sn, sv, sspec, light)) continue;
+            if (PRUNE && light_adds_nothing(n, v, spec, light)) continue;
             L.r = light;
             L.path = (L.path & 0xFFFEu) | 1u | (li << 16);              // a shadow query of light li; depth and sample (or job marks) stay
-            start_query(L, sc, PRUNE, root_ref);
+            scr.f(3) = lighting;
+            L.state = ST_INNER; new_query = true;
             return;
         }
+        RTX_SECTION(2)      // the lights loop with its shadow query starts
         if (job) {
             // the job is done: the level's total lighting goes to the pixel's owner, and if this was the last party at
             // work on the pixel, this lane finishes it
             const uint32_t owner = job_owner(L.path);
             px.id = scr.id - lane + owner;
-            px.total(d) = scr.f(3);
+            px.total(d) = lighting;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             const uint32_t left = __hip_atomic_fetch_sub(pend + owner, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - 1u;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -753,42 +814,35 @@ __device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScen
             finish = true;
         } else {
             // Color * double truncates each channel (color.hpp:47-53)
-            const int32_t pos = scr.i(0);
-            const DevMat &mt = sc.mats[pos];
-            const double total = scr.f(3);
-            const int lr = to_int(mt.color[0] * total), lg = to_int(mt.color[1] * total), lb = to_int(mt.color[2] * total);
-            const double refl = mt.reflectivity;
+            const int lr = to_int(colour0 * lighting), lg = to_int(colour1 * lighting), lb = to_int(colour2 * lighting);
             if (d == (uint32_t)rp.depth || refl < 0) {                  // scene.hpp:115-117
                 cr = lr; cg = lg; cb = lb;
                 path_done = true;
             } else {
                 scr.colour(d, 0) = lr; scr.colour(d, 1) = lg; scr.colour(d, 2) = lb;
                 scr.refl(d) = refl;
-                const V3 v = {scr.f(0), scr.f(1), scr.f(2)};
-                L.r = reflect_ray(v, ld3(sc.tris[pos].n));              // scene.hpp:119
+                L.r = reflect_ray(v, n);                                // scene.hpp:119
                 L.path = make_path(0, d + 1, s, 0);
-                start_query(L, sc, PRUNE, root_ref);
+                L.state = ST_INNER; new_query = true;
                 return;
             }
         }
     }
+    RTX_SECTION(3)          // local colour, reflection query start
     uint32_t levels = d;       // levels below the innermost colour
     bool inner_waits = false;  // TAIL: the innermost colour is a level whose lighting is a job's
     if (TAIL && elsewhere) {
         // the level's record holds the triangle's colour until the blend, where the job's total meets it
-        const int32_t pos = scr.i(0);
-        const DevMat &mt = sc.mats[pos];
-        scr.colour(d, 0) = mt.color[0]; scr.colour(d, 1) = mt.color[1]; scr.colour(d, 2) = mt.color[2];
+        scr.colour(d, 0) = colour0; scr.colour(d, 1) = colour1; scr.colour(d, 2) = colour2;
         scr.waiting() |= (int32_t)(1u << d);
-        const double refl = mt.reflectivity;
         if (d == (uint32_t)rp.depth || refl < 0) {                      // scene.hpp:115-117
             path_done = true;
             inner_waits = true;
         } else {
             scr.refl(d) = refl;
-            L.r = reflect_ray(muls(L.r, -1.0), ld3(sc.tris[pos].n));    // scene.hpp:119; L.r is still the ray that hit
+            L.r = reflect_ray(v, n);                                    // scene.hpp:119; v = -(the ray that hit)
             L.path = make_path(0, d + 1, s, 0);
-            start_query(L, sc, PRUNE, root_ref);
+            L.state = ST_INNER; new_query = true;
             return;
         }
     }
@@ -833,16 +887,29 @@ __device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScen
     } else {
         // localColor * (1 - reflectivity) + reflectedColor * reflectivity (scene.hpp:122), innermost first
         while (levels > 0) {
-            levels--;
-            const int lr = scr.colour(levels, 0), lg = scr.colour(levels, 1), lb = scr.colour(levels, 2);
-            const double refl = scr.refl(levels);
-            const double keep = 1 - refl;
+            // the records of two levels per trip to memory
+            const bool two = levels >= 2u;
+            const uint32_t la = levels - 1u, lb_ = two ? levels - 2u : la;
+            const int ar = scr.colour(la, 0), ag = scr.colour(la, 1), ab = scr.colour(la, 2);
+            const double arefl = scr.refl(la);
+            const int br = scr.colour(lb_, 0), bg = scr.colour(lb_, 1), bb = scr.colour(lb_, 2);
+            const double brefl = scr.refl(lb_);
+            issued();
             // int + int wraps on both machines
-            cr = (int)((uint32_t)to_int(lr * keep) + (uint32_t)to_int(cr * refl));
-            cg = (int)((uint32_t)to_int(lg * keep) + (uint32_t)to_int(cg * refl));
-            cb = (int)((uint32_t)to_int(lb * keep) + (uint32_t)to_int(cb * refl));
+            const double akeep = 1 - arefl;
+            cr = (int)((uint32_t)to_int(ar * akeep) + (uint32_t)to_int(cr * arefl));
+            cg = (int)((uint32_t)to_int(ag * akeep) + (uint32_t)to_int(cg * arefl));
+            cb = (int)((uint32_t)to_int(ab * akeep) + (uint32_t)to_int(cb * arefl));
+            if (two) {
+                const double bkeep = 1 - brefl;
+                cr = (int)((uint32_t)to_int(br * bkeep) + (uint32_t)to_int(cr * brefl));
+                cg = (int)((uint32_t)to_int(bg * bkeep) + (uint32_t)to_int(cg * brefl));
+                cb = (int)((uint32_t)to_int(bb * bkeep) + (uint32_t)to_int(cb * brefl));
+            }
+            levels -= two ? 2u : 1u;
         }
     }
+    RTX_SECTION(4)          // blend
     // putPixel (src/main.cpp:90-94) + the clamp of saveCanvas (src/main.cpp:107)
     if (TAIL || rp.spp == 1) {
         if (rp.rgb) {
@@ -857,7 +924,7 @@ __device__ __forceinline__ void shade_step(Lane &L, PixelSum &acc, const DevScen
     acc.r += clamp255(cr); acc.g += clamp255(cg); acc.b += clamp255(cb);
     if (s + 1 < (uint32_t)rp.spp) {
         primary_ray(L, sc, rp, (int)(L.pix & 0xFFFFu), (int)(L.pix >> 16), s + 1, rp.n_frames > 1 ? L.out / rp.frame_pixels : 0u);
-        start_query(L, sc, PRUNE, root_ref);
+        L.state = ST_INNER; new_query = true;
         return;
     }
     const int spp = rp.spp;
@@ -881,7 +948,20 @@ struct Wave {
     uint32_t blocks_x, per_tile, home_queue;
     // STATS: rounds the wave ran of each kind and the lanes that took part (kept by lane 0)
     unsigned long long rounds[3], lane_steps[3];
+#ifdef RTX_EXPERIMENT_KINDTIME
+    // MEASUREMENT ONLY (tools/kind_time.py): shader-clock cycles this wave spent in the steps of each kind (node pair,
+    // triangle, shading and refill) and in the rounds' own bookkeeping; leaves through the wave log
+    unsigned long long kind_cycles[4];
+    unsigned long long section_cycles[8];   // inside the shading step, see RTX_SECTION; [7] = the rest of the step
+#endif
 };
+#ifdef RTX_EXPERIMENT_KINDTIME
+#define RTX_KIND_BEGIN const unsigned long long kind_t0 = cycles_now();
+#define RTX_KIND_END(k) w.kind_cycles[k] += cycles_now() - kind_t0;
+#else
+#define RTX_KIND_BEGIN
+#define RTX_KIND_END(k)
+#endif
 
 // The next 8x8 block for a wave whose current one is used up: from the queue of this wave's XCD first (its tiles are
 // screen neighbours, so the XCD's L2 keeps seeing the same part of the BVH), then from the other queues.  Which queue
@@ -925,8 +1005,15 @@ __device__ __forceinline__ void draw_block(Wave &w, const DevRender &rp, uint32_
 template <bool PRUNE, bool STATS, bool TAIL>
 __device__ __forceinline__ bool wave_loop(Lane &L, PixelSum &acc, Wave &w, const DevScene &sc, const DevRender &rp, const Hot &hot,
                                           uint32_t *stack, uint32_t stride, const Scratch &scr, Counters &c, uint32_t *pend,
-                                          uint32_t lane, uint64_t gw, bool jobs_possible) {
+                                          uint32_t *surf, uint32_t lane, uint64_t gw, bool jobs_possible) {
     for (;;) {
+#ifdef RTX_EXPERIMENT_KINDTIME
+        const unsigned long long round_t0 = cycles_now();
+        struct RoundClock {                 // every way out of the round's body adds the round to the total
+            Wave &w; unsigned long long t0;
+            __device__ ~RoundClock() { w.kind_cycles[3] += cycles_now() - t0; }
+        } round_clock{w, round_t0};
+#endif
         const unsigned long long m_inner = __ballot(L.state == ST_INNER);
         const unsigned long long m_leaf = __ballot(L.state == ST_LEAF);
         const unsigned long long m_shade = __ballot(L.state == ST_SHADE);
@@ -944,13 +1031,23 @@ __device__ __forceinline__ bool wave_loop(Lane &L, PixelSum &acc, Wave &w, const
         const bool pick_leaf = !pick_inner && w_leaf >= w_shade;
         if (pick_inner || (all_kinds && n_inner) || n_inner >= hot.also_lanes) {
             if (STATS && lane == 0) { w.rounds[0]++; w.lane_steps[0] += n_inner; }
+            RTX_KIND_BEGIN
             if (L.state == ST_INNER) inner_step<PRUNE, STATS>(L, hot, stack, stride, c);
+            RTX_KIND_END(0)
         }
         if (pick_leaf || (all_kinds && n_leaf) || n_leaf >= hot.also_leaf) {
             if (STATS) { const int k = __popcll(__ballot(L.state == ST_LEAF)); if (lane == 0) { w.rounds[1]++; w.lane_steps[1] += k; } }
+            RTX_KIND_BEGIN
             if (L.state == ST_LEAF) leaf_step<PRUNE, STATS>(L, hot, stack, stride, c);
+            RTX_KIND_END(1)
         }
         if ((!pick_inner && !pick_leaf) || (all_kinds && n_shade) || n_shade >= hot.also_shade) {
+#ifdef RTX_EXPERIMENT_KINDTIME
+            struct KindClock {
+                Wave &w; unsigned long long t0;
+                __device__ ~KindClock() { w.kind_cycles[2] += cycles_now() - t0; }
+            } shade_clock{w, cycles_now()};
+#endif
             unsigned long long handed_over = 0ull;
             if (TAIL) {
                 // closest-hit results that found a surface meet the lanes without work, one pair at a time (rare, and
@@ -979,16 +1076,34 @@ __device__ __forceinline__ bool wave_loop(Lane &L, PixelSum &acc, Wave &w, const
                 if ((handed_over >> lane) & 1ull) pend[lane] += 1u;     // one more party at work on this lane's pixel
             }
             if (STATS) { const int k = __popcll(__ballot(L.state == ST_SHADE)); if (lane == 0) { w.rounds[2]++; w.lane_steps[2] += k; } }
+            bool new_query = false;     // the lane has a new ray in L.o, L.r, L.path: a shadow ray, a reflection or a camera ray
             if (L.state == ST_SHADE)
-                shade_step<PRUNE, STATS, TAIL>(L, acc, sc, rp, scr, c, hot.root_ref, ((handed_over >> lane) & 1ull) != 0ull, pend, lane);
+                {
+#ifdef RTX_EXPERIMENT_KINDTIME
+                    const unsigned long long t_ = cycles_now();
+                    shade_step<PRUNE, STATS, TAIL>(L, acc, sc, rp, scr, c, ((handed_over >> lane) & 1ull) != 0ull, pend, surf, hot.lights, lane, new_query, w.section_cycles);
+                    w.section_cycles[6] += cycles_now() - t_;      // the whole step
+#else
+                    shade_step<PRUNE, STATS, TAIL>(L, acc, sc, rp, scr, c, ((handed_over >> lane) & 1ull) != 0ull, pend, surf, hot.lights, lane, new_query);
+#endif
+                }
             if (TAIL) {
                 if (L.state == ST_FETCH) L.state = ST_DONE;             // the queues are empty
+                if (new_query) start_query(L, sc, PRUNE, hot.root_ref);
                 continue;
             }
             // hand pixels to the lanes without one, in lane order
             unsigned long long need = __ballot(L.state == ST_FETCH);
             while (need) {
-                if (w.cursor == 64u && !w.drained) draw_block(w, rp, (uint32_t)rp.n_frames, lane, gw);
+                if (w.cursor == 64u && !w.drained) {
+#ifdef RTX_EXPERIMENT_KINDTIME
+                    const unsigned long long t_ = cycles_now();
+                    draw_block(w, rp, (uint32_t)rp.n_frames, lane, gw);
+                    w.section_cycles[5] += cycles_now() - t_;
+#else
+                    draw_block(w, rp, (uint32_t)rp.n_frames, lane, gw);
+#endif
+                }
                 if (w.cursor == 64u) {                                  // nothing left anywhere
                     if (L.state == ST_FETCH) L.state = ST_DONE;
                     break;
@@ -1005,7 +1120,8 @@ __device__ __forceinline__ bool wave_loop(Lane &L, PixelSum &acc, Wave &w, const
                                                                          : row * (uint32_t)rp.W + col) + w.frame * rp.frame_pixels;
                         acc = {0, 0, 0};
                         primary_ray(L, sc, rp, (int)col, (int)row, 0, w.frame);
-                        start_query(L, sc, PRUNE, hot.root_ref);
+                        L.state = ST_INNER;
+                        new_query = true;
                     }
                 }
                 const uint32_t n_need = (uint32_t)__popcll(need);
@@ -1014,6 +1130,8 @@ __device__ __forceinline__ bool wave_loop(Lane &L, PixelSum &acc, Wave &w, const
                 // was outside the window
                 need = __ballot(L.state == ST_FETCH);
             }
+            // every new ray of the round starts here: shadow rays, reflections, camera rays
+            if (new_query) start_query(L, sc, PRUNE, hot.root_ref);
         }
     }
 }
@@ -1361,15 +1479,23 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
     const uint32_t stride = 31u - (uint32_t)__builtin_clz(rp.stack_stride);
     // the top of the tree goes into LDS behind the block's stacks
     const uint32_t n_top = sc.n_top_pairs;
-    d2 *top_lds = reinterpret_cast<d2 *>(lds + (uint32_t)(sc.bvh_depth + 2) * rp.stack_stride);
-    // the row between the stacks and the table: parties at work on each lane's pixel (lighting jobs, see shade_step)
-    uint32_t *pend = lds + (uint32_t)(sc.bvh_depth + 1) * rp.stack_stride + (threadIdx.x & ~63u);
+    // (the layout behind the stacks is render_lds_bytes()'s: two rows of a word per lane, the lights, then the table)
+    double *lights_lds = reinterpret_cast<double *>(lds + (uint32_t)(sc.bvh_depth + 3) * rp.stack_stride);
+    d2 *top_lds = reinterpret_cast<d2 *>(lights_lds + 4u * kLdsLights);
+    // first row behind the stacks: parties at work on each lane's pixel (lighting jobs, see shade_step)
+    const uint32_t wave_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));    // wave-uniform, and known to be
+    uint32_t *pend = lds + (uint32_t)(sc.bvh_depth + 1) * rp.stack_stride + wave_first;
+    // second row: the triangle of the surface whose shadow queries the lane is running
+    uint32_t *surf = lds + (uint32_t)(sc.bvh_depth + 2) * rp.stack_stride + wave_first;
     {
         const d2 *src = reinterpret_cast<const d2 *>(sc.top);
         for (uint32_t i = threadIdx.x; i < n_top * 8u; i += blockDim.x) top_lds[i] = src[i];
+        const uint32_t n_lights = sc.n_point + sc.n_dir;
+        if (n_lights <= kLdsLights && threadIdx.x < 4u * n_lights)
+            lights_lds[threadIdx.x] = (threadIdx.x & 3u) == 0u ? sc.lights[threadIdx.x >> 2].intensity : sc.lights[threadIdx.x >> 2].v[(threadIdx.x & 3u) - 1u];
         __syncthreads();
     }
-    const Hot hot = {sc.nodes, sc.tris, top_lds, n_top ? kTopFlag : 0u, sc.n_point, rp.w_inner, rp.w_leaf, rp.w_shade, rp.tail_lanes, rp.also_lanes, rp.also_leaf, rp.also_shade};
+    const Hot hot = {sc.nodes, sc.tris, top_lds, lights_lds, n_top ? kTopFlag : 0u, sc.n_point, rp.w_inner, rp.w_leaf, rp.w_shade, rp.tail_lanes, rp.also_lanes, rp.also_leaf, rp.also_shade};
     uint32_t *stack = lds + threadIdx.x;
     const Scratch scr = {rp.scratch_f64, rp.scratch_i32, rp.scratch_lanes, gw * 64u + lane, (uint32_t)rp.depth};
     Counters c;
@@ -1395,6 +1521,10 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
     // HW_REG_XCC_ID (id 20), bits 3:0: the XCD this wave runs on
     w.home_queue = rp.n_queues > 1 ? ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % rp.n_queues : 0u;
     for (int i = 0; i < 3; i++) { w.rounds[i] = 0; w.lane_steps[i] = 0; }
+#ifdef RTX_EXPERIMENT_KINDTIME
+    for (int i = 0; i < 4; i++) w.kind_cycles[i] = 0;
+    for (int i = 0; i < 8; i++) w.section_cycles[i] = 0;
+#endif
 
     // Lighting jobs.  Once the queues are empty a wave runs on with ever fewer lanes, and what then sets the length of
     // the launch is the longest pixel: up to depth + 1 closest-hit queries and as many rounds of shadow queries, one
@@ -1406,12 +1536,12 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
     const bool jobs_possible = rp.spp == 1 && (sc.n_point + sc.n_dir) != 0u && rp.lighting_jobs != 0;
     if (STAGED) {
         stage_loop<PRUNE, STATS>(L, w, sc, rp, hot, stack, stride, scr, c, pend, lane, gw);
-    } else if (wave_loop<PRUNE, STATS, false>(L, acc, w, sc, rp, hot, stack, stride, scr, c, pend, lane, gw, jobs_possible)) {
+    } else if (wave_loop<PRUNE, STATS, false>(L, acc, w, sc, rp, hot, stack, stride, scr, c, pend, surf, lane, gw, jobs_possible)) {
         // lanes only run out of work when every queue is empty: from here on no lane takes a new pixel, and the
         // pixels in progress count one party each, their owner's chain
         pend[lane] = (L.state == ST_DONE) ? 0u : 1u;
         if (L.state != ST_DONE) scr.waiting() = 0;
-        wave_loop<PRUNE, STATS, true>(L, acc, w, sc, rp, hot, stack, stride, scr, c, pend, lane, gw, jobs_possible);
+        wave_loop<PRUNE, STATS, true>(L, acc, w, sc, rp, hot, stack, stride, scr, c, pend, surf, lane, gw, jobs_possible);
     }
     if (STATS && rp.stats) {
         for (int i = 0; i < 9; i++)
@@ -1425,6 +1555,12 @@ __global__ void __launch_bounds__(256, RTX_WAVES_PER_EU) render_kernel(const Dev
     if (rp.wave_log && lane == 0) {
         rp.wave_log[4 * gw] = wave_t0;
         rp.wave_log[4 * gw + 1] = wall_clock64();
+#ifdef RTX_EXPERIMENT_KINDTIME
+        rp.wave_log[4 * gw + 2] = w.kind_cycles[0] | (w.kind_cycles[1] << 32);
+        rp.wave_log[4 * gw + 3] = w.kind_cycles[2] | (w.kind_cycles[3] << 32);
+        // the sections of the shading step: summed over the waves behind the log's rows (the caller allocates 8 more words there)
+        for (int i = 0; i < 8; i++) atomicAdd(&rp.wave_log[4 * (unsigned long long)gridDim.x * waves_per_block + i], w.section_cycles[i]);
+#endif
     }
     // first wave start / last wave end of the launch, one pair of atomics per block.  Both are maxima over a pair
     // the caller zeroed (the start as its complement), so that no clearing dispatch has to precede the launch.
