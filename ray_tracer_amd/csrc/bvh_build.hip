@@ -1455,8 +1455,8 @@ __global__ void flatten_nodes_kernel(const rtx_bvh_node *__restrict__ in, uint32
         DevNode d{};
         const double nan = __longlong_as_double(0x7ff8000000000000ll);
         for (int k = 0; k < 3; k++) { d.bmin[k] = nan; d.bmax[k] = nan; }
-        d.pad[0] = first_of(in[0]);            // slot 0 pairs with the root
-        d.pad[1] = (uint32_t)in[0].count;
+        d.pad[0] = 0;                          // slot 0 pairs with the root
+        d.pad[1] = node_entry(1u, first_of(in[0]), (uint32_t)in[0].count);
         out[0] = d;
     }
     if (i >= n_nodes) return;
@@ -1472,11 +1472,11 @@ __global__ void flatten_nodes_kernel(const rtx_bvh_node *__restrict__ in, uint32
     }
     d.count = (uint32_t)h.count;
     d.first = first_of(h);
-    // an even slot (i + 1 even) is the first record of a sibling pair and repeats its sibling's {first, count}
+    // an even slot (i + 1 even) is the left node of a sibling pair: the references to itself and to its sibling
     if ((i & 1u) && i + 1 < n_nodes) {
         const rtx_bvh_node sib = in[i + 1];
-        d.pad[0] = first_of(sib);
-        d.pad[1] = (uint32_t)sib.count;
+        d.pad[0] = node_entry(i + 1u, d.first, d.count);
+        d.pad[1] = node_entry(i + 2u, first_of(sib), (uint32_t)sib.count);
     }
     out[i + 1] = d;
     if (!ok) atomicAnd(tame, 0);

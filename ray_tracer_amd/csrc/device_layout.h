@@ -20,14 +20,24 @@
 
 namespace rtx {
 
+// How the walk refers to a node it may enter next, in one word -- the form its traversal stack holds, so that entering
+// a child and entering a node that comes off the stack are the same few instructions:
+//   bit 31 = 0: an inner node, bits 30..0 = slot of its left child (or kTopFlag | pair index, see below)
+//   bit 31 = 1: a leaf, bits 30..28 = count - 1 (1..7 triangles), bits 27..0 = first triangle position; the value 7 in
+//               bits 30..28 marks a bigger leaf, then bits 27..0 hold the node's own slot and its header is read.
+// (Triangle positions and node slots stay below 2^28; checked when the scene is created.)
+constexpr uint32_t node_entry(uint32_t slot, uint32_t first, uint32_t count) {
+    return count == 0u ? first : (count <= 7u ? (0x80000000u | ((count - 1u) << 28) | first) : (0xF0000000u | slot));
+}
+
 struct alignas(64) DevNode {
     double bmin[3];
     double bmax[3];
     uint32_t first;   // inner: slot of the left child (right = first + 1); leaf: first triangle position
     uint32_t count;   // 0 = inner
-    // even slot (the first record of a sibling pair): {first, count} of the odd sibling once more, so that a pair test
-    // reads 112 contiguous bytes (this record and the sibling's box) and not the sibling's last 16;
-    // odd slot: unused in `nodes`, pad[0] = the pair's slot in `nodes` in the top table
+    // the left node of a sibling pair (wherever an inner node's `first` points): node_entry() of itself and of its
+    // sibling, so that a pair test reads 112 contiguous bytes (this record and the sibling's box) and finds both
+    // children's references ready-made; other nodes: unused
     uint32_t pad[2];
 };
 static_assert(sizeof(DevNode) == 64, "DevNode");

@@ -528,16 +528,16 @@ static int scene_create_from_host_impl(const rtx_host_scene *hs, int32_t device,
         d.count = (uint32_t)h.count;
         d.first = h.count == 0 ? (uint32_t)(h.first + 1) : (uint32_t)h.first;
     }
-    // The first record of a sibling pair repeats the second one's {first, count} (see DevNode).  A pair is wherever
+    // The left record of a sibling pair holds the references to both nodes of the pair (see DevNode).  A pair is wherever
     // an inner node points: the reference's builder puts every left child at an odd index (even slot), a caller's
     // tree may number its nodes differently, so the pairs are taken from the inner nodes and not from the slot parity.
-    nodes[0].pad[0] = nodes[1].first;      // the pair (0, 1) a walk starts with
-    nodes[0].pad[1] = nodes[1].count;
+    nodes[0].pad[0] = 0;                   // the pair (0, 1) a walk starts with
+    nodes[0].pad[1] = rtx::node_entry(1u, nodes[1].first, nodes[1].count);
     for (uint64_t i = 0; i < m; i++) {
         if (s.nodes[i].count != 0 || s.nodes[i].first == 0 || s.nodes[i].first + 1 >= m) continue;   // leaf, or a blanked gap
         const uint64_t left = s.nodes[i].first + 1;            // slot of the left child; validate_bvh keeps left + 1 <= m
-        nodes[left].pad[0] = nodes[left + 1].first;
-        nodes[left].pad[1] = nodes[left + 1].count;
+        nodes[left].pad[0] = rtx::node_entry((uint32_t)left, nodes[left].first, nodes[left].count);
+        nodes[left].pad[1] = rtx::node_entry((uint32_t)left + 1u, nodes[left + 1].first, nodes[left + 1].count);
     }
     std::vector<rtx::DevTri> tris(n);
     std::vector<rtx::DevMat> mats(n);

@@ -468,25 +468,9 @@ __device__ __forceinline__ void start_query(Lane &L, const DevScene &sc, bool pr
 #endif
 }
 
-// A stack entry says where to continue without another trip to memory:
-//   bit 31 = 0: an inner node, bits 30..0 = slot of its left child
-//   bit 31 = 1: a leaf, bits 30..28 = count - 1 (1..7 triangles), bits 27..0 = first triangle
-//               position; the value 7 in bits 30..28 marks a bigger leaf, then bits 27..0
-//               hold the node's slot and its header is read.
-// (Triangle positions and node slots stay below 2^28; checked when the scene is created.)
-__device__ __forceinline__ uint32_t stack_entry(uint32_t slot, uint32_t first, uint32_t count) {
-    const uint32_t small_leaf = 0x80000000u | ((count - 1u) << 28) | first;
-    const uint32_t leaf = count <= 7u ? small_leaf : (0xF0000000u | slot);
-    return count == 0u ? first : leaf;
-}
-
-__device__ __forceinline__ void pop_node(Lane &L, const DevNode *nodes, const uint32_t *stack, uint32_t stride) {   // stride: log2 of the lanes per stack level
-    if (L.sp == 0) {
-        L.state = ST_SHADE;
-        return;
-    }
-    L.sp--;
-    const uint32_t e = stack[L.sp << stride];
+// Enters the node a reference names (node_entry() in device_layout.h): a child of the pair just tested, or what came
+// off the stack.
+__device__ __forceinline__ void enter_node(Lane &L, uint32_t e, const DevNode *nodes) {
     const bool leaf = (e & 0x80000000u) != 0;
     L.first = leaf ? (e & 0x0FFFFFFFu) : e;
     L.count = leaf ? ((e >> 28) & 7u) + 1u : 0u;
@@ -498,6 +482,15 @@ __device__ __forceinline__ void pop_node(Lane &L, const DevNode *nodes, const ui
     }
 }
 
+__device__ __forceinline__ void pop_node(Lane &L, const DevNode *nodes, const uint32_t *stack, uint32_t stride) {   // stride: log2 of the lanes per stack level
+    if (L.sp == 0) {
+        L.state = ST_SHADE;
+        return;
+    }
+    L.sp--;
+    enter_node(L, stack[L.sp << stride], nodes);
+}
+
 template <bool PRUNE, bool STATS>
 __device__ __forceinline__ void inner_step(Lane &L, const Hot &hot, uint32_t *stack, uint32_t stride, Counters &c) {
     const DevNode *nodes = hot.nodes;
@@ -506,11 +499,9 @@ __device__ __forceinline__ void inner_step(Lane &L, const Hot &hot, uint32_t *st
     // for), else to memory
     d2 q0, q1, q2, q3, q4, q5, q6;
     const bool in_top = (L.first & kTopFlag) != 0;
-    uint32_t pair_slot = L.first;          // the pair's slot in `nodes` (a table pair carries it in its second record's padding)
     if (in_top) {
         const d2 *line = hot.top + (L.first & 0xFFFFu) * 8u;
         q0 = line[0]; q1 = line[1]; q2 = line[2]; q3 = line[3]; q4 = line[4]; q5 = line[5]; q6 = line[6];
-        pair_slot = (uint32_t)__double2loint(line[7].y);
     } else {
         // 112 of the pair's 128 bytes: the first record whole (its padding repeats the sibling's {first, count}) and the
         // sibling's box -- seven loads; every byte a wave asks its L1 for counts here
@@ -550,24 +541,25 @@ __device__ __forceinline__ void inner_step(Lane &L, const Hot &hot, uint32_t *st
         ha = ha && !beyond_a;
         hb = hb && !beyond_b;
     }
-    // {first, count} of both children sit in the fourth 16-byte piece of the first record
-    const uint32_t af = (uint32_t)__double2loint(q3.x), ac = (uint32_t)__double2hiint(q3.x);
-    const uint32_t bf = (uint32_t)__double2loint(q3.y), bc = (uint32_t)__double2hiint(q3.y);
-    // next node: the only child hit, or of two the nearer one (PRUNE) / the left one; the other
-    // one of two goes on the stack
+    // the references to both nodes sit ready-made in the fourth 16-byte piece of the first record
+    const uint32_t ea = (uint32_t)__double2loint(q3.y), eb = (uint32_t)__double2hiint(q3.y);
+    // next node: the only child hit, or of two the nearer one (PRUNE) / the left one, while the other one of two goes on
+    // the stack; with no child hit, what comes off the stack
     const bool take_b = hb && (!ha || (PRUNE && tb < ta));
     if (ha && hb) {
-        // the child that is not taken
-        stack[L.sp << stride] = stack_entry(take_b ? pair_slot : pair_slot + 1u, take_b ? af : bf, take_b ? ac : bc);
+        stack[L.sp << stride] = take_b ? ea : eb;
         L.sp++;
     }
-    if (ha || hb) {
-        L.first = take_b ? bf : af;
-        L.count = take_b ? bc : ac;
-        L.state = L.count ? ST_LEAF : ST_INNER;
-    } else {
-        pop_node(L, nodes, stack, stride);
+    uint32_t e = take_b ? eb : ea;
+    if (!(ha || hb)) {
+        if (L.sp == 0) {
+            L.state = ST_SHADE;
+            return;
+        }
+        L.sp--;
+        e = stack[L.sp << stride];
     }
+    enter_node(L, e, nodes);
 }
 
 template <bool PRUNE, bool STATS>
@@ -1633,9 +1625,8 @@ __global__ void __launch_bounds__(64) top_table_kernel(const DevNode *nodes, Dev
         // an inner child whose pair still fits is referred to by its place in the table; slot 0 is no node
         if (s != 0 && a.count == 0 && n < max_pairs) { slot_of[n] = a.first; a.first = kTopFlag | n; n++; }
         if (b.count == 0 && n < max_pairs) { slot_of[n] = b.first; b.first = kTopFlag | n; n++; }
-        a.pad[0] = b.first;      // the sibling's {first, count} once more, as in `nodes`
-        a.pad[1] = b.count;
-        b.pad[0] = s;
+        a.pad[0] = node_entry(s, a.first, a.count);          // the references to both nodes, as in `nodes`
+        a.pad[1] = node_entry(s + 1u, b.first, b.count);
         top[2 * i] = a;
         top[2 * i + 1] = b;
     }
