@@ -261,7 +261,7 @@ int rtx_render(rtx_scene *scene, const rtx_render_params *p, uint8_t *rgb_out, i
  * rtx_render_end() waits for that slot's frame and copies it into the caller's arrays (either may
  * be NULL; hit ids only if asked for at begin).  With frame n+1 begun before frame n is ended, the
  * copy to host memory and the end of a frame's kernel overlap the next frame's render: about
- * 2.9 ms per 4K frame of the dragon scene delivered to host memory, against 4.1 ms call by call.
+ * 2.8 ms per 4K frame of the dragon scene delivered to host memory, against 4.0 ms call by call.
  *     rtx_render_begin(s, &p, 0, 0);
  *     for (n = 0; n < frames; n++) {
  *         if (n + 1 < frames) rtx_render_begin(s, &p, (n + 1) % 2, 0);

@@ -79,8 +79,8 @@ struct DevScene {
     const DevLight *lights;   // point lights first, then directional
     // The top of the tree once more, for the render kernel's LDS: `n_top_pairs` sibling pairs
     // in breadth-first order (pair 0 = slots 0 and 1), 128 bytes each.  Inside it an inner
-    // child whose own pair is in the table carries kTopFlag | pair index as `first`, and
-    // pad[0] of a pair's second record holds the pair's slot in `nodes`.
+    // child whose own pair is in the table carries kTopFlag | pair index as `first` (and as
+    // its reference in the left record's padding).
     const DevNode *top;
     uint32_t n_top_pairs, top_pad;
     uint32_t n_nodes, n_tris, n_point, n_dir;

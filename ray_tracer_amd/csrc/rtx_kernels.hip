@@ -494,7 +494,7 @@ __device__ __forceinline__ void pop_node(Lane &L, const DevNode *nodes, const ui
 template <bool PRUNE, bool STATS>
 __device__ __forceinline__ void inner_step(Lane &L, const Hot &hot, uint32_t *stack, uint32_t stride, Counters &c) {
     const DevNode *nodes = hot.nodes;
-    // the sibling pair is one 128-byte line: eight 16-byte loads, one round trip -- to LDS for a pair
+    // the sibling pair is one 128-byte line: seven 16-byte loads of it, one round trip -- to LDS for a pair
     // of the top table (every walk starts there, and the vector memory path is what the kernel waits
     // for), else to memory
     d2 q0, q1, q2, q3, q4, q5, q6;
@@ -503,7 +503,7 @@ __device__ __forceinline__ void inner_step(Lane &L, const Hot &hot, uint32_t *st
         const d2 *line = hot.top + (L.first & 0xFFFFu) * 8u;
         q0 = line[0]; q1 = line[1]; q2 = line[2]; q3 = line[3]; q4 = line[4]; q5 = line[5]; q6 = line[6];
     } else {
-        // 112 of the pair's 128 bytes: the first record whole (its padding repeats the sibling's {first, count}) and the
+        // 112 of the pair's 128 bytes: the first record whole (its padding holds the references to both nodes) and the
         // sibling's box -- seven loads; every byte a wave asks its L1 for counts here
         const d2 *line = reinterpret_cast<const d2 *>(nodes + L.first);
         q0 = line[0]; q1 = line[1]; q2 = line[2];
