@@ -90,6 +90,30 @@ def test_soup_point_lights_rotations_bit_exact(seed, mode):
 
 
 @pytest.mark.parametrize("mode", [rt.TRAVERSAL_REFERENCE, rt.TRAVERSAL_PRUNED])
+@pytest.mark.parametrize("n_lights", [8, 11])
+def test_many_lights(mode, n_lights):
+    """Up to eight lights a render block keeps in LDS, a scene with more is lit from memory: both against the oracle,
+    with the lights' order (point lights first, computeTotalLighting, scene.hpp:130-142) deciding the sum's rounding."""
+    v, col, spec, refl, cam = soup(8, n=250)
+    rng = np.random.default_rng(n_lights)
+    n_point = n_lights // 2
+    cam = dict(cam, ambient=0.05,
+               point_lights=[(float(rng.uniform(0.05, 0.2)), tuple(rng.uniform(-6, 6, size=3) + np.array([0, 0, 4.0]))) for _ in range(n_point)],
+               directional_lights=[(float(rng.uniform(0.05, 0.2)), tuple(rng.uniform(-1, 1, size=3))) for _ in range(n_lights - n_point)])
+    dev = rt.Scene(rt.HostScene.from_arrays(v, col, spec, refl, **cam))
+    ora = OracleScene.from_arrays(v, col, spec, refl, **cam)
+    want = ora.render(128, 96, depth=2)
+    got = dev.render(128, 96, depth=2, traversal=mode, want_stats=True)
+    assert np.array_equal(got.hit, want["hit"])
+    assert np.array_equal(got.rgb, want["rgb_u8"])
+    if mode == rt.TRAVERSAL_REFERENCE:
+        have = got.stats.as_dict()
+        have.pop("kernel_ms")
+        assert have == want["census"].as_dict()
+    dev.close()
+
+
+@pytest.mark.parametrize("mode", [rt.TRAVERSAL_REFERENCE, rt.TRAVERSAL_PRUNED])
 def test_caller_tree_with_left_children_at_even_indices(mode):
     """The same tree numbered from two (one unused record after the root): sibling pairs then start at odd device
     slots.  The frame and the census must not notice."""
