@@ -3,7 +3,8 @@
 (RTX_LIB=<that library>), whose waves add up the shader-clock cycles they spend inside node-pair steps, triangle steps
 and shading / refill steps and in all rounds together, and leave the sums in the wave log.  The rounds of each kind come
 from a second launch with the work counters on.
-usage: RTX_LIB=gpurun_variants/librtx_kindtime.so tools/kind_time.py [scene] [family]"""
+build: make -C ray_tracer_amd/csrc ../librtx_kindtime.so
+usage: RTX_LIB=ray_tracer_amd/librtx_kindtime.so tools/kind_time.py [scene] [family]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Histogram of node-pair steps per query of one 4K frame, by query kind (needs a library built with
--DRTX_EXPERIMENT_STEPHIST, named by RTX_LIB).  usage: tools/step_histogram.py <scene> <family>"""
+-DRTX_EXPERIMENT_STEPHIST, named by RTX_LIB: make -C ray_tracer_amd/csrc ../librtx_stephist.so).  usage: tools/step_histogram.py <scene> <family>"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
